@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: coordinate-samples/sec of one full training step (on-device batch
+generation -> forward -> MSE -> backward -> [RCCL all-reduce] -> Adam) on a synthetic volume.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg3]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`:
+one rank per GPU, z-slab sharding of the volume, equal local batch (weak scaling), ONE
+all-reduce of the flat gradient buffer per step.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs; the metric is quoted on a 256^3 volume at 1/2/4/8 GPUs):
+  cfg4  256^3, hash L16 F2 T2^19 base 16 growth 1.4 + ReLU MLP 32-128-128-1, B=2^18 per GPU  (default)
+  cfg2  128^3, hash L16 F2 T2^19 16->512 + ReLU MLP 32-64-64-1, B=2^18
+  cfg3  256^3, SIREN 3-256x5-1, coords in [-1,1], B=2^20
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # exact-f32 matrix rate (no xf32 on gfx950)
+
+WORKLOADS = {
+    "cfg4": dict(shape=(256, 256, 256), model="hash", finest=16 * 1.4 ** 15, hidden=128,
+                 batch=1 << 18, lr=5e-3, norm_siren=False),
+    "cfg2": dict(shape=(128, 128, 128), model="hash", finest=512, hidden=64, batch=1 << 18,
+                 lr=5e-3, norm_siren=False),
+    "cfg3": dict(shape=(256, 256, 256), model="siren", hidden=256, batch=1 << 20, lr=1e-4,
+                 norm_siren=True),
+}
+
+
+def build_model(w):
+    import torch
+    from mri_interpolation_amd import models
+    torch.manual_seed(1337)  # reference launcher.py:30
+    if w["model"] == "hash":
+        return models.HashMLP(dim_in=3, n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                              base_resolution=16, finest_resolution=w["finest"],
+                              dim_hidden=w["hidden"], dim_out=1, n_layers=3,
+                              activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
+                              lr=w["lr"])
+    return models.SirenNet(dim_in=3, dim_hidden=w["hidden"], dim_out=1, n_layers=5, lr=w["lr"])
+
+
+def phase_model(w, step, n_params):
+    """Algorithmic bytes / flops per step of each timed phase."""
+    b = w["batch"]
+    dims = [l.weight.shape[1] for l in step.layers] + [step.layers[-1].weight.shape[0]]
+    mac = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    out = {"mlp_fwd": ("mfma", 2.0 * mac * b), "mlp_bwd": ("mfma", 4.0 * mac * b),
+           "adam": ("hbm", 28.0 * n_params)}
+    if step.encoder is not None:
+        e = step.encoder
+        corners = (1 << e.dim) * e.n_levels * e.n_features_per_level * 4
+        per_coord = 4 * e.dim + corners + e.output_dim * 4  # coords + table rows + features
+        out["hashgrid_fwd"] = ("hbm", float(per_coord) * b)
+        out["hashgrid_bwd"] = ("hbm", float(per_coord) * b)
+    return out
+
+
+def cpu_baseline(w, name):
+    """The oracle (CPU restatement of the reference's step) timed on the host cores, on a
+    bounded sample of the same workload."""
+    import torch
+    from oracle import train as otrain
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 1 << 15 if w["model"] == "hash" else 1 << 14
+    if w["model"] == "hash":
+        m = otrain.HashMlpModel(3, 16, 2, 19, 16, w["finest"], hidden=[w["hidden"]] * 2, seed=1)
+    else:
+        m = otrain.SirenModel(3, w["hidden"], 1, 5, seed=1)
+    g = torch.Generator().manual_seed(0)
+    lo = -1.0 if w["norm_siren"] else 0.0
+    batches = [(torch.rand(b, 3, generator=g) * (1 - lo) + lo, torch.rand(b, 1, generator=g))
+               for _ in range(2)]
+    opt = None
+    _, opt = otrain.train_steps(m, batches[:1], w["lr"], opt)  # warm-up
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 10.0 and steps < 20:
+        _, opt = otrain.train_steps(m, [batches[steps % 2]], w["lr"], opt)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=b * steps / dt, unit="coord-samples/s", cores=cores, kind="port",
+                sample=f"{steps} oracle train steps (PyTorch-CPU restatement of the reference "
+                       f"step) of {name} at batch {b} instead of {w['batch']}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--psnr-steps", type=int, default=500,
+                    help="total training steps before the PSNR evaluation (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bwd-method", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from mri_interpolation_amd import _lib, datamodules, parallel, trainer
+    _lib.load()  # no fallback: fail before touching the GPU if the HIP library is missing
+
+    rank, world, local = parallel.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    w = WORKLOADS[args.workload]
+
+    # synthetic volume in HBM, this rank's z-slab, on-device batch generation
+    vol = datamodules.phantom_volume(w["shape"], device=dev)
+    ds = datamodules.MriImage(volume=vol, norm_siren=w["norm_siren"], device=dev)
+    lo, hi = parallel.voxel_range(ds.shape, rank, world)
+    loader = datamodules.DeviceLoader(ds, w["batch"], shuffle=True, lo=lo, hi=hi,
+                                      seed=1337 + rank)
+    model = build_model(w).to(dev)
+    opt = model.configure_optimizers()
+    step = trainer.FusedStep(model, opt, world)
+    step.bwd_method = args.bwd_method
+    n_params = sum(p.numel() for p in model.parameters())
+    coords = torch.empty(w["batch"], 3, device=dev)
+    target = torch.empty(w["batch"], 1, device=dev)
+    per_epoch = (hi - lo) // w["batch"]
+    counter = [0]
+
+    def one_step():
+        k = counter[0]
+        counter[0] += 1
+        loader.set_epoch(k // per_epoch)
+        with step._phase("coord_gen"):
+            idx = loader.indices((k % per_epoch) * w["batch"], w["batch"])
+            ds.batch(idx, coords, target)
+        return step.train_step(coords, target)
+
+    for _ in range(args.warmup):
+        one_step()
+    step.phase_events = {}
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+    phases = step.phase_ms()
+    step.phase_events = None
+
+    # PSNR vs ground-truth voxels at a fixed step count (outside the timed region)
+    psnr = None
+    if args.psnr_steps > 0:
+        while counter[0] < args.psnr_steps:
+            one_step()
+        if rank == 0:
+            preds = []
+            with torch.no_grad():
+                for x, _ in datamodules.DeviceLoader(ds, 1 << 20, shuffle=False):
+                    preds.append(step.forward(x)[0].clone())
+            psnr = dict(steps=counter[0], db=trainer.psnr(torch.cat(preds), ds.pixels)
+                        if not w["norm_siren"] else
+                        trainer.psnr((torch.cat(preds) + 1) / 2, (ds.pixels + 1) / 2))
+    if rank != 0:
+        return
+
+    ms = elapsed / args.steps * 1e3
+    value = w["batch"] * world * args.steps / elapsed
+    pm = phase_model(w, step, n_params)
+    dominant = max((k for k in phases if k in pm), key=lambda k: phases[k])
+    bound, amount = pm[dominant]
+    sec = phases[dominant] * 1e-3
+    if bound == "hbm":
+        roof = dict(bound="hbm", achieved=amount / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    else:
+        roof = dict(bound="mfma", achieved=amount / sec / 1e12, peak=MFMA_F32_PEAK_TF,
+                    unit="TFLOP/s")
+    roof.update(frac=roof["achieved"] / roof["peak"], traffic=None, kernel=dominant,
+                ms_per_launch=phases[dominant])
+    result = {
+        "metric": "coord-samples/sec (train)", "value": value, "unit": "coord-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} analytic "
+                               f"phantom, {w['model']}, batch {w['batch']} coords per GPU",
+                   "global_batch": w["batch"] * world, "params": n_params,
+                   "parallelism": f"dp{world} z-slab" if world > 1 else "single GPU"},
+        "roofline": roof,
+        "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
+        "final_loss": float(loss),
+    }
+    if step.encoder is not None:  # whole-step HBM fraction as north_star defines it
+        e = step.encoder
+        per_coord = 4 * e.dim + 4 + 2 * (1 << e.dim) * e.output_dim * 4 + 28.0 * n_params / w["batch"]
+        result["step_hbm_frac"] = value / world * per_coord / (HBM_PEAK_GBS * 1e9)
+    if psnr is not None:
+        result["psnr"] = psnr
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(w, args.workload)
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * mri_inr.h -- C ABI of the MI355X (gfx950) hot path for Benjamin-Fouquet/mri_interpolation.
+ *
+ * The reference is pure Python: its hot path sits behind Python class surfaces, not an FFI
+ * (SURVEY.md section 8b).  Each entry point below names the reference op chain it replaces
+ * (file:line into the reference repository); the Python classes in mri_interpolation_amd/ bind
+ * these with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's data_ptr())
+ *     unless the parameter is documented as host memory; the library never allocates,
+ *     frees or retains memory;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it and never
+ *     synchronise; the library keeps no global state besides the last-error string;
+ *   - all matrices are float32, row-major, with an explicit leading dimension in elements;
+ *   - return value 0 = success, negative = mri_status; mri_last_error() returns a
+ *     thread-local message for the last failure.  No C++ exception crosses this boundary.
+ */
+#ifndef MRI_INR_H
+#define MRI_INR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRI_MAX_LEVELS 32
+#define MRI_MAX_DIM 7 /* len(PRIMES), reference encoding.py:40,90-92 */
+
+typedef enum mri_status {
+  MRI_OK = 0,
+  MRI_ERR_INVALID_ARGUMENT = -1,
+  MRI_ERR_UNSUPPORTED = -2,
+  MRI_ERR_LAUNCH = -3
+} mri_status;
+
+typedef enum mri_activation {
+  MRI_ACT_IDENTITY = 0,
+  MRI_ACT_RELU = 1, /* nn.ReLU,  reference models.py:31,54 */
+  MRI_ACT_SINE = 2, /* sin(w0*z), reference models.py:108-114 */
+  MRI_ACT_GELU = 3  /* nn.GELU (erf form), reference models.py:672,736 */
+} mri_activation;
+
+/* How mri_linear_backward_data turns dL/d(activation output) into dL/d(pre-activation). */
+typedef enum mri_deriv_mode {
+  MRI_DERIV_NONE = 0,     /* no multiply (identity / network input)                     */
+  MRI_DERIV_MUL = 1,      /* multiply by a stored derivative matrix (sine, gelu)        */
+  MRI_DERIV_RELU_MASK = 2 /* multiply by (stored activation output > 0)                 */
+} mri_deriv_mode;
+
+/* Host-side description of a multiresolution hash grid (HOST memory, copied by value).
+ * Mirrors what MultiResHashGrid / MultiResHashGridV2 compute in __init__
+ * (reference encoding.py:168-185, 310-330): one resolution per level and axis, one table
+ * size per level, tables concatenated in one flat (sum T_l, F) float32 array. */
+typedef struct mri_grid_desc {
+  int32_t dim;        /* D, 1..MRI_MAX_DIM                                   */
+  int32_t n_levels;   /* L, 1..MRI_MAX_LEVELS                                */
+  int32_t n_features; /* F, 1..8                                             */
+  int32_t reserved;
+  float resolution[MRI_MAX_LEVELS][MRI_MAX_DIM + 1]; /* res_l on axis d (float32, as the
+                                                        reference multiplies in float32)  */
+  uint32_t table_size[MRI_MAX_LEVELS];               /* T_l, any value >= 1 (not only 2^k) */
+  uint64_t table_offset[MRI_MAX_LEVELS];             /* first row of level l in the flat table */
+} mri_grid_desc;
+
+/* Library / build identification: "mri_inr <version> gfx950". */
+const char* mri_version(void);
+const char* mri_last_error(void);
+/* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n); results stay within
+ * fp32 summation-order noise. */
+int mri_set_option(const char* name, int32_t value);
+
+/* ---- hash-grid encoding --------------------------------------------------------------
+ * Replaces, per level, the op chain of _HashGrid.forward / _HashGridV2.forward
+ * (reference encoding.py:108-128, 232-270) incl. fast_hash (encoding.py:69-78), and the
+ * torch.cat over levels (encoding.py:190-191, 335-336).
+ *   x    (n, D) row-major coordinates.
+ *   out  element (row i, level l, feature f) is written to
+ *        out[l * out_level_stride + i * out_row_stride + f * out_feat_stride].
+ *        Reference layout (n, L*F): level stride F, row stride L*F, feature stride 1.
+ *        Feature-major layout (L*F, n) used inside the fused trainer (coalesced stores,
+ *        read back by mri_linear_forward with x_row_stride 1): level stride F*n, row
+ *        stride 1, feature stride n.
+ */
+int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
+                         const float* table, float* out, int64_t out_level_stride,
+                         int64_t out_row_stride, int64_t out_feat_stride, void* stream);
+
+/* Replaces the autograd of the same chain: aten::embedding_dense_backward per level plus
+ * the mul/sum backward (reference encoding.py:127-128).
+ * d_table (sum T_l, F) is ACCUMULATED into (caller zeroes it).  d_out uses the same
+ * three-stride addressing as `out` above.
+ *   method 0 = choose per level; 1 = global float atomics; 2 = LDS-privatised owner-computes
+ */
+int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x, const float* d_out,
+                          int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
+                          int64_t dout_feat_stride, float* d_table, int32_t method, void* stream);
+
+/* ---- fully connected layers (f32 MFMA) ------------------------------------------------
+ * y = act(w0 * (x W^T + b))   with W (N, K) row-major as nn.Linear / SirenLayer store it.
+ * Replaces F.linear + activation: reference models.py:46-56 (BaseMLP.layers),
+ * models.py:153-156 (SirenLayer.forward), models.py:730-736 (HashMLP decoder Linear+act).
+ *   x element (m, k) at x[m*x_row_stride + k*x_col_stride]  (x_col_stride 1 = row-major,
+ *     x_row_stride 1 = feature-major (K, M) as written by the level-major encoder output).
+ *   deriv (optional, (M, ldd)) receives d act / d z  (w0*cos(w0 z) for sine, gelu'(z));
+ *     pass NULL for identity / relu (relu's mask is recovered from y).
+ *   w0 is only used by MRI_ACT_SINE.
+ */
+int mri_linear_forward(const float* x, int64_t x_row_stride, int64_t x_col_stride,
+                       const float* weight, const float* bias /* may be NULL */, int64_t m,
+                       int32_t n, int32_t k, int32_t activation, float w0, float* y,
+                       int64_t ldy, float* deriv /* may be NULL */, int64_t ldd, void* stream);
+
+/* dx = (dy W) (.) g   where g is chosen by deriv_mode from `deriv` ((M, K), leading dim ldd):
+ * the gradient w.r.t. the PREVIOUS layer's pre-activation (autograd of F.linear followed by
+ * the previous activation's backward).  dx element (m, k) at dx[m*dx_row_stride + k*dx_col_stride]
+ * (deriv_mode must be MRI_DERIV_NONE when dx_col_stride != 1).
+ */
+int mri_linear_backward_data(const float* dy, int64_t lddy, const float* weight, int64_t m,
+                             int32_t n, int32_t k, int32_t deriv_mode, const float* deriv,
+                             int64_t ldd, float* dx, int64_t dx_row_stride,
+                             int64_t dx_col_stride, void* stream);
+
+/* d_weight (N, K) += dy^T x ;  d_bias (N) += column sums of dy (d_bias may be NULL).
+ * Accumulates with float atomics (caller zeroes the gradient buffers once per step).
+ * x addressed with the same two strides as in mri_linear_forward. */
+int mri_linear_backward_weight(const float* dy, int64_t lddy, const float* x,
+                               int64_t x_row_stride, int64_t x_col_stride, int64_t m, int32_t n,
+                               int32_t k, float* d_weight, float* d_bias, void* stream);
+
+/* In-place dy *= g (same deriv modes as above) -- activation after the LAST Linear
+ * (BaseMLP keeps one, reference models.py:54). */
+int mri_apply_deriv(float* dy, int64_t lddy, int32_t deriv_mode, const float* deriv,
+                    int64_t ldd, int64_t m, int32_t n, void* stream);
+
+/* ---- loss ------------------------------------------------------------------------------
+ * F.mse_loss(y, y_pred) (reference models.py:64): loss_out[0] += mean((pred-target)^2)
+ * (device scalar, caller zeroes), d_pred = 2 (pred - target) / (count * grad_divisor) if
+ * d_pred != NULL.  pred/target/d_pred are contiguous with `count` elements.
+ * grad_divisor > 1 pre-averages gradients over data-parallel ranks. */
+int mri_mse_loss(const float* pred, const float* target, int64_t count, float grad_divisor,
+                 float* loss_out, float* d_pred, void* stream);
+
+/* ---- optimiser -------------------------------------------------------------------------
+ * torch.optim.Adam, single step over one flat buffer (reference models.py:68-70; defaults
+ * betas (0.9, 0.999), eps 1e-8, no weight decay).  `step` is the 1-based step count.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t count, double lr, double beta1, double beta2, double eps,
+                  int32_t step, float grad_scale, void* stream);
+
+/* ---- coordinate-batch producer ------------------------------------------------------------
+ * Replaces MriImage.__getitem__ + DataLoader(shuffle=True) collate (reference
+ * datamodules.py:140-172, 198-205) with on-device generation.
+ * mri_sample_indices: idx_out[i] = lo + perm_epoch((first + i) mod (hi-lo)), a keyed
+ *   bijection of [0, hi-lo) (without-replacement shuffle, one key per epoch/seed).
+ * mri_gather_batch: flat C-order voxel index -> coordinates (row-major (n, D)) through the
+ *   per-axis linspace tables (`axes` = concatenation of the D axis arrays built with
+ *   torch.linspace on the host, axis_offset[d] = start of axis d) and targets from `volume`.
+ *   shape / axis_offset are HOST arrays of length D. */
+int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int64_t hi, int64_t n,
+                       int64_t* idx_out, void* stream);
+int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* shape,
+                     const float* axes, const int64_t* axis_offset, const float* volume,
+                     float* coords_out, float* target_out /* may be NULL */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRI_INR_H */

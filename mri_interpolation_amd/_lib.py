@@ -1,0 +1,98 @@
+"""ctypes binding of include/mri_inr.h (the C-ABI drop-in boundary).
+
+The library is required: there is no CPU or PyTorch fallback for the hot path.  If
+`libmri_inr.so` is missing or fails to load, every op raises.
+"""
+import ctypes as C
+import os
+
+MAX_LEVELS = 32
+MAX_DIM = 7
+
+ACT_IDENTITY, ACT_RELU, ACT_SINE, ACT_GELU = 0, 1, 2, 3
+DERIV_NONE, DERIV_MUL, DERIV_RELU_MASK = 0, 1, 2
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmri_inr.so")
+
+
+class GridDesc(C.Structure):
+    """struct mri_grid_desc (host memory)."""
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("n_features", C.c_int32),
+        ("reserved", C.c_int32),
+        ("resolution", (C.c_float * (MAX_DIM + 1)) * MAX_LEVELS),
+        ("table_size", C.c_uint32 * MAX_LEVELS),
+        ("table_offset", C.c_uint64 * MAX_LEVELS),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_F = C.c_float
+_D = C.c_double
+
+# name -> argtypes; every function returns int except the two string getters
+SIGNATURES = {
+    "mri_set_option": [C.c_char_p, _I32],
+    "mri_hashgrid_forward": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _I64, _P],
+    "mri_hashgrid_backward": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32, _P],
+    "mri_linear_forward": [_P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _P, _I64, _P,
+                           _I64, _P],
+    "mri_linear_backward_data": [_P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _I64, _I64,
+                                 _P],
+    "mri_linear_backward_weight": [_P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
+    "mri_apply_deriv": [_P, _I64, _I32, _P, _I64, _I64, _I32, _P],
+    "mri_mse_loss": [_P, _P, _I64, _F, _P, _P, _P],
+    "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
+    "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
+    "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
+}
+STRING_GETTERS = ["mri_version", "mri_last_error"]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libmri_inr.so once; raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `python -m mri_interpolation_amd.build` "
+            "(hipcc, gfx950).  The MI355X hot path has no CPU/PyTorch fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name in STRING_GETTERS:
+        getattr(lib, name).restype = C.c_char_p
+        getattr(lib, name).argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mri_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libmri_inr {what} failed ({rc}): {msg}")
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def version() -> str:
+    return load().mri_version().decode()
+
+
+def set_option(name: str, value: int):
+    call("mri_set_option", name.encode(), int(value))

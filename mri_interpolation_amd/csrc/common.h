@@ -1,0 +1,45 @@
+// Shared helpers for the gfx950 hot-path library (see include/mri_inr.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "mri_inr.h"
+
+namespace mri {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// Thread-local last-error string, set by MRI_FAIL and read through mri_last_error().
+char* error_buffer();
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MRI_REQUIRE(cond, ...)                                        \
+  do {                                                                \
+    if (!(cond)) return ::mri::fail(MRI_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MRI_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MRI_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Tuning knobs (process-wide, speed only -- never change results beyond fp32 summation order).
+struct Options {
+  int xcd_affinity = 1;       // map hash-grid levels to XCDs (blockIdx % 8) so a level's table stays in one L2
+  int bwd_lds_max_parts = 64; // levels needing more LDS partitions than this fall back to global atomics
+};
+Options& options();
+
+}  // namespace mri

@@ -1,0 +1,400 @@
+// Fully connected layers on the f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces F.linear + activation and its autograd (reference models.py:46-56, 153-156,
+// 230-233, 730-736).  gfx950 has no xf32/TF32, and BASELINE.json asks for 1e-5 relative
+// fp32 parity, so every product runs on the exact-f32 MFMA (k-ordered fmaf chain).
+//
+// One kernel template covers the three GEMMs of a layer.  It computes
+//        C[i][j] = sum_c P(i, c) * Q(j, c)
+// for operands addressed with two strides each (element (o, c) at base + o*os + c*cs), so
+// that row-major activations, feature-major encoder output, W and W^T all use the same code:
+//   forward          i = batch row m, j = output unit n, c = input unit k
+//   backward (data)  i = m,           j = k,             c = n       (Q = W read "transposed")
+//   backward (weight) i = n,          j = k,             c = m       (contraction over the batch,
+//                                                                    split over blockIdx.z, f32 atomics)
+// A 256-thread workgroup (4 waves) owns a BI x BJ tile; each wave owns TI x TJ MFMA tiles of
+// 32x32 and keeps them in registers across the contraction loop.  Both operand tiles are
+// staged through LDS in 32-deep chunks, in whichever of two images makes the staging stores
+// and the fragment reads conflict-free for that operand's memory order:
+//   "row" image  [o][c], leading dim 33   (operand contiguous along the contraction)
+//   "col" image  [c][o], leading dim O+4  (operand contiguous along the outer index)
+#include <math.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mri {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KB = 32;        // contraction chunk staged per iteration
+constexpr int kThreads = 256;
+
+enum Epilogue { EPI_FORWARD = 0, EPI_BACKWARD_DATA = 1, EPI_ATOMIC = 2 };
+
+struct Operand {
+  const float* ptr;
+  int64_t os, cs;  // strides of the outer and the contraction index (elements)
+  int mode;        // 0 scalar loads, 1 float4 along c ("row" image), 2 float4 along o ("col" image)
+};
+
+struct GemmArgs {
+  Operand p, q;
+  int64_t I, J, C;   // extents
+  int64_t c_per_split;
+  float* out;        // C[i*ldo + j]
+  int64_t ldo;
+  // EPI_FORWARD
+  const float* bias;
+  int act;
+  float w0;
+  float* deriv_out;
+  int64_t ldd_out;
+  // EPI_BACKWARD_DATA
+  int deriv_mode;
+  const float* deriv_in;
+  int64_t ldd_in;
+  // EPI_ATOMIC
+  float* rowsum_out;  // += sum_c P(i, c) for blocks with blockIdx.y == 0 (d_bias)
+};
+
+template <int O>
+struct TileImage {
+  static constexpr int kRowLd = KB + 1;
+  static constexpr int kColLd = O + 4;
+  static constexpr int kFloats = (O * kRowLd > KB * kColLd) ? O * kRowLd : KB * kColLd;
+};
+
+// Fill one operand tile (O outer x KB contraction) of LDS, zero-filling out-of-range elements.
+template <int O>
+__device__ __forceinline__ void stage(float* __restrict__ lds, const Operand& op, int64_t o0,
+                                      int64_t o_end, int64_t c0, int64_t c_end) {
+  const int t = threadIdx.x;
+  if (op.mode == 1) {
+    constexpr int kVec = O * (KB / 4);
+#pragma unroll
+    for (int v = t; v < kVec; v += kThreads) {
+      const int o = v / (KB / 4), c4 = (v % (KB / 4)) * 4;
+      const int64_t go = o0 + o, gc = c0 + c4;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (go < o_end) {
+        const float* src = op.ptr + go * op.os + gc;
+        if (gc + 3 < c_end) {
+          r = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (gc + 0 < c_end) r.x = src[0];
+          if (gc + 1 < c_end) r.y = src[1];
+          if (gc + 2 < c_end) r.z = src[2];
+        }
+      }
+      float* dst = lds + o * TileImage<O>::kRowLd + c4;
+      dst[0] = r.x, dst[1] = r.y, dst[2] = r.z, dst[3] = r.w;
+    }
+  } else if (op.mode == 2) {
+    constexpr int kVec = (O / 4) * KB;
+#pragma unroll
+    for (int v = t; v < kVec; v += kThreads) {
+      const int c = v / (O / 4), o4 = (v % (O / 4)) * 4;
+      const int64_t go = o0 + o4, gc = c0 + c;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gc < c_end) {
+        const float* src = op.ptr + gc * op.cs + go;
+        if (go + 3 < o_end) {
+          r = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (go + 0 < o_end) r.x = src[0];
+          if (go + 1 < o_end) r.y = src[1];
+          if (go + 2 < o_end) r.z = src[2];
+        }
+      }
+      *reinterpret_cast<float4*>(lds + c * TileImage<O>::kColLd + o4) = r;
+    }
+  } else {
+    constexpr int kElems = O * KB;
+    for (int v = t; v < kElems; v += kThreads) {
+      const int o = v / KB, c = v % KB;
+      const int64_t go = o0 + o, gc = c0 + c;
+      float r = 0.f;
+      if (go < o_end && gc < c_end) r = op.ptr[go * op.os + gc * op.cs];
+      lds[o * TileImage<O>::kRowLd + c] = r;
+    }
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float z) {
+  return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+  return cdf + z * pdf;
+}
+
+template <int WI, int WJ, int TI, int TJ, int EPI>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs a) {
+  constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
+  static_assert(WI * WJ * kWave == kThreads, "4 waves per workgroup");
+  __shared__ float lds[TileImage<BI>::kFloats + TileImage<BJ>::kFloats];
+  float* __restrict__ ps = lds;
+  float* __restrict__ qs = lds + TileImage<BI>::kFloats;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int64_t i0 = (int64_t)blockIdx.x * BI, j0 = (int64_t)blockIdx.y * BJ;
+  const int64_t c_begin = (int64_t)blockIdx.z * a.c_per_split;
+  const int64_t c_end = min(a.C, c_begin + a.c_per_split);
+
+  // per-lane fragment addresses inside the two images
+  const int p_so = a.p.mode == 2 ? 1 : TileImage<BI>::kRowLd;
+  const int p_sc = a.p.mode == 2 ? TileImage<BI>::kColLd : 1;
+  const int q_so = a.q.mode == 2 ? 1 : TileImage<BJ>::kRowLd;
+  const int q_sc = a.q.mode == 2 ? TileImage<BJ>::kColLd : 1;
+  const float* __restrict__ pf = ps + (wi * TI * 32 + l31) * p_so + lh * p_sc;
+  const float* __restrict__ qf = qs + (wj * TJ * 32 + l31) * q_so + lh * q_sc;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+  float rowsum = 0.f;
+  const bool want_rowsum = EPI == EPI_ATOMIC && a.rowsum_out != nullptr && blockIdx.y == 0;
+
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += KB) {
+    __syncthreads();
+    stage<BI>(ps, a.p, i0, a.I, c0, c_end);
+    stage<BJ>(qs, a.q, j0, a.J, c0, c_end);
+    __syncthreads();
+    const int kc = (int)min((int64_t)KB, c_end - c0);
+    if (want_rowsum && threadIdx.x < BI) {
+      const float* row = ps + threadIdx.x * p_so;
+      for (int c = 0; c < kc; ++c) rowsum += row[c * p_sc];
+    }
+    auto mfma_steps = [&](const int k_lo, const int k_hi) {
+#pragma unroll
+      for (int kk = k_lo; kk < k_hi; kk += 2) {
+        float pa[TI], qb[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) pa[ti] = pf[ti * 32 * p_so + kk * p_sc];
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) qb[tj] = qf[tj * 32 * q_so + kk * q_sc];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+            acc[ti][tj] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ti], qb[tj], acc[ti][tj], 0, 0, 0);
+      }
+    };
+    if (kc == KB) {
+      mfma_steps(0, KB);
+    } else {  // ragged tail of the contraction (zero-filled by stage): stop at the last pair
+      for (int kk = 0; kk < kc; kk += 2) mfma_steps(kk, kk + 2);
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 f32 MFMA: col = lane & 31,
+  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int64_t j = j0 + (wj * TJ + tj) * 32 + l31;
+      if (j >= a.J) continue;
+      float bj = 0.f;
+      if (EPI == EPI_FORWARD && a.bias) bj = a.bias[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (i >= a.I) continue;
+        float v = acc[ti][tj][r];
+        if (EPI == EPI_FORWARD) {
+          v += bj;
+          float d = 1.0f;
+          switch (a.act) {
+            case MRI_ACT_RELU:
+              v = fmaxf(v, 0.f);
+              break;
+            case MRI_ACT_SINE: {
+              const float u = a.w0 * v;
+              float s, c;
+              sincosf(u, &s, &c);
+              v = s;
+              d = a.w0 * c;
+            } break;
+            case MRI_ACT_GELU:
+              d = gelu_grad_f(v);
+              v = gelu_f(v);
+              break;
+            default:
+              break;
+          }
+          a.out[i * a.ldo + j] = v;
+          if (a.deriv_out) a.deriv_out[i * a.ldd_out + j] = d;
+        } else if (EPI == EPI_BACKWARD_DATA) {
+          if (a.deriv_mode == MRI_DERIV_MUL) {
+            v *= a.deriv_in[i * a.ldd_in + j];
+          } else if (a.deriv_mode == MRI_DERIV_RELU_MASK) {
+            v = a.deriv_in[i * a.ldd_in + j] > 0.f ? v : 0.f;
+          }
+          a.out[i * a.ldo + j] = v;
+        } else {
+          atomicAdd(a.out + i * a.ldo + j, v);
+        }
+      }
+    }
+  }
+  if (want_rowsum && threadIdx.x < BI && i0 + threadIdx.x < a.I)
+    atomicAdd(a.rowsum_out + i0 + threadIdx.x, rowsum);
+}
+
+// elementwise dy *= g
+__global__ __launch_bounds__(256) void apply_deriv_kernel(float* __restrict__ dy, int64_t lddy,
+                                                          int mode, const float* __restrict__ g,
+                                                          int64_t ldd, int64_t m, int n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m * n) return;
+  const int64_t r = e / n, c = e % n;
+  const float gv = g[r * ldd + c];
+  float v = dy[r * lddy + c];
+  if (mode == MRI_DERIV_MUL)
+    v *= gv;
+  else if (mode == MRI_DERIV_RELU_MASK)
+    v = gv > 0.f ? v : 0.f;
+  dy[r * lddy + c] = v;
+}
+
+// ------------------------------------------------------------------------------ host side
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+Operand make_operand(const float* ptr, int64_t os, int64_t cs) {
+  Operand o{ptr, os, cs, 0};
+  if (cs == 1 && os % 4 == 0 && aligned16(ptr))
+    o.mode = 1;
+  else if (os == 1 && cs % 4 == 0 && aligned16(ptr))
+    o.mode = 2;
+  return o;
+}
+
+template <int WI, int WJ, int TI, int TJ, int EPI>
+int launch_cfg(GemmArgs& a, int splits, hipStream_t st) {
+  constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
+  const int64_t gi = ceil_div(a.I, BI), gj = ceil_div(a.J, BJ);
+  if (gi >= (1ll << 31) || gj > 65535 || splits > 65535)
+    return fail(MRI_ERR_INVALID_ARGUMENT, "gemm grid too large");
+  hipLaunchKernelGGL((gemm_kernel<WI, WJ, TI, TJ, EPI>), dim3((unsigned)gi, (unsigned)gj, splits),
+                     dim3(kThreads), 0, st, a);
+  return check_launch("gemm_kernel");
+}
+
+// Pick the tile that wastes the least MFMA work for an I x J output.
+template <int EPI>
+int launch(GemmArgs& a, int splits, hipStream_t st) {
+  const int64_t I = a.I, J = a.J;
+  if (I <= 32) return launch_cfg<1, 4, 1, 1, EPI>(a, splits, st);  // 32 x 128
+  if (J <= 32) return launch_cfg<4, 1, 1, 1, EPI>(a, splits, st);  // 128 x 32
+  if (J <= 64) {
+    if (I <= 64) return launch_cfg<2, 2, 1, 1, EPI>(a, splits, st);  // 64 x 64
+    return launch_cfg<2, 2, 2, 1, EPI>(a, splits, st);               // 128 x 64
+  }
+  if (I <= 64) return launch_cfg<2, 2, 1, 2, EPI>(a, splits, st);  // 64 x 128
+  return launch_cfg<2, 2, 2, 2, EPI>(a, splits, st);               // 128 x 128
+}
+
+}  // namespace
+}  // namespace mri
+
+using namespace mri;
+
+extern "C" int mri_linear_forward(const float* x, int64_t x_row_stride, int64_t x_col_stride,
+                                  const float* weight, const float* bias, int64_t m, int32_t n,
+                                  int32_t k, int32_t activation, float w0, float* y, int64_t ldy,
+                                  float* deriv, int64_t ldd, void* stream) {
+  MRI_REQUIRE(m >= 0 && n >= 1 && k >= 1, "bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+  MRI_REQUIRE(activation >= MRI_ACT_IDENTITY && activation <= MRI_ACT_GELU, "bad activation %d",
+              activation);
+  if (m == 0) return MRI_OK;
+  MRI_REQUIRE(x && weight && y, "NULL device pointer");
+  MRI_REQUIRE(ldy >= n && (!deriv || ldd >= n), "leading dimension smaller than n");
+  GemmArgs a{};
+  a.p = make_operand(x, x_row_stride, x_col_stride);
+  a.q = make_operand(weight, k, 1);
+  a.I = m, a.J = n, a.C = k, a.c_per_split = k;
+  a.out = y, a.ldo = ldy;
+  a.bias = bias, a.act = activation, a.w0 = w0;
+  a.deriv_out = deriv, a.ldd_out = ldd;
+  return launch<EPI_FORWARD>(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int mri_linear_backward_data(const float* dy, int64_t lddy, const float* weight,
+                                        int64_t m, int32_t n, int32_t k, int32_t deriv_mode,
+                                        const float* deriv, int64_t ldd, float* dx,
+                                        int64_t dx_row_stride, int64_t dx_col_stride,
+                                        void* stream) {
+  MRI_REQUIRE(m >= 0 && n >= 1 && k >= 1, "bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+  MRI_REQUIRE(deriv_mode >= MRI_DERIV_NONE && deriv_mode <= MRI_DERIV_RELU_MASK,
+              "bad deriv_mode %d", deriv_mode);
+  if (m == 0) return MRI_OK;
+  MRI_REQUIRE(dy && weight && dx, "NULL device pointer");
+  MRI_REQUIRE(deriv_mode == MRI_DERIV_NONE || deriv, "deriv_mode %d needs a deriv matrix",
+              deriv_mode);
+  GemmArgs a{};
+  a.C = n, a.c_per_split = n;
+  if (dx_col_stride == 1) {
+    a.p = make_operand(dy, lddy, 1);    // P(i = m, c = n)
+    a.q = make_operand(weight, 1, k);   // Q(j = k, c = n) = W[n][k]
+    a.I = m, a.J = k;
+    a.out = dx, a.ldo = dx_row_stride;
+    a.deriv_mode = deriv_mode, a.deriv_in = deriv, a.ldd_in = ldd;
+    return launch<EPI_BACKWARD_DATA>(a, 1, (hipStream_t)stream);
+  }
+  // feature-major dx: compute the transposed product so that stores stay coalesced
+  MRI_REQUIRE(dx_row_stride == 1, "dx must have a unit stride");
+  MRI_REQUIRE(deriv_mode == MRI_DERIV_NONE, "deriv_mode needs row-major dx");
+  a.p = make_operand(weight, 1, k);   // P(i = k, c = n)
+  a.q = make_operand(dy, lddy, 1);    // Q(j = m, c = n)
+  a.I = k, a.J = m;
+  a.out = dx, a.ldo = dx_col_stride;
+  a.act = MRI_ACT_IDENTITY;
+  return launch<EPI_FORWARD>(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int mri_linear_backward_weight(const float* dy, int64_t lddy, const float* x,
+                                          int64_t x_row_stride, int64_t x_col_stride, int64_t m,
+                                          int32_t n, int32_t k, float* d_weight, float* d_bias,
+                                          void* stream) {
+  MRI_REQUIRE(m >= 0 && n >= 1 && k >= 1, "bad shape m=%lld n=%d k=%d", (long long)m, n, k);
+  if (m == 0) return MRI_OK;
+  MRI_REQUIRE(dy && x && d_weight, "NULL device pointer");
+  GemmArgs a{};
+  a.p = make_operand(dy, 1, lddy);                     // P(i = n, c = m)
+  a.q = make_operand(x, x_col_stride, x_row_stride);   // Q(j = k, c = m)
+  a.I = n, a.J = k, a.C = m;
+  a.out = d_weight, a.ldo = k;
+  a.rowsum_out = d_bias;
+  // split the batch so that ~2 workgroups per CU are in flight; each split is a multiple of KB
+  const int64_t tiles = ceil_div(n, 128) * ceil_div(k, 128);
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(512 / tiles, ceil_div(m, 4 * KB)));
+  a.c_per_split = ceil_div(ceil_div(m, splits), KB) * KB;
+  splits = ceil_div(m, a.c_per_split);
+  return launch<EPI_ATOMIC>(a, (int)splits, (hipStream_t)stream);
+}
+
+extern "C" int mri_apply_deriv(float* dy, int64_t lddy, int32_t deriv_mode, const float* deriv,
+                               int64_t ldd, int64_t m, int32_t n, void* stream) {
+  MRI_REQUIRE(m >= 0 && n >= 1, "bad shape");
+  MRI_REQUIRE(deriv_mode >= MRI_DERIV_NONE && deriv_mode <= MRI_DERIV_RELU_MASK,
+              "bad deriv_mode %d", deriv_mode);
+  if (m == 0 || deriv_mode == MRI_DERIV_NONE) return MRI_OK;
+  MRI_REQUIRE(dy && deriv, "NULL device pointer");
+  const int64_t blocks = ceil_div(m * n, 256);
+  hipLaunchKernelGGL(apply_deriv_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, dy, lddy, deriv_mode, deriv, ldd, m, (int)n);
+  return check_launch("apply_deriv_kernel");
+}

@@ -1,0 +1,252 @@
+// Loss, optimiser and the on-device coordinate-batch producer for gfx950, plus the library's
+// small host-side state (last error, tuning options).
+//
+//   mse_loss      F.mse_loss(y, y_pred) and its gradient          reference models.py:61-66
+//   adam_step     torch.optim.Adam defaults, one flat buffer      reference models.py:68-70
+//   sample/gather MriImage.__getitem__ + shuffled DataLoader      reference datamodules.py:140-172,198-205
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mri {
+
+char* error_buffer() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+
+Options& options() {
+  static Options o;
+  return o;
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------ loss
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ pred,
+                                                       const float* __restrict__ target,
+                                                       int64_t count, float inv_count,
+                                                       float grad_scale,
+                                                       float* __restrict__ loss_out,
+                                                       float* __restrict__ d_pred) {
+  float local = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count;
+       e += (int64_t)gridDim.x * 256) {
+    const float diff = pred[e] - target[e];
+    local += diff * diff;
+    if (d_pred) d_pred[e] = diff * grad_scale;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  __shared__ float partial[4];
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(loss_out, (partial[0] + partial[1] + partial[2] + partial[3]) * inv_count);
+}
+
+// ------------------------------------------------------------------------------------ Adam
+// Same operation order as torch's single-tensor Adam:
+//   m = m + (g - m) * (1 - b1)            (Tensor.lerp_)
+//   v = v * b2 + (1 - b2) * g * g         (mul_ then addcmul_)
+//   p = p + (-step_size * m) / (sqrt(v) / sqrt(bc2) + eps)    (addcdiv_)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
+                                                   const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t count, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float neg_step_size,
+                                                   float bc2_sqrt, float eps, float grad_scale) {
+  const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (base >= count) return;
+  if (base + 3 < count) {
+    float4 pv = *reinterpret_cast<float4*>(p + base);
+    const float4 gv4 = *reinterpret_cast<const float4*>(g + base);
+    float4 mv = *reinterpret_cast<float4*>(m + base);
+    float4 vv = *reinterpret_cast<float4*>(v + base);
+    float* pp = &pv.x;
+    const float* gp = &gv4.x;
+    float* mp = &mv.x;
+    float* vp = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gp[e] * grad_scale;
+      mp[e] = mp[e] + (gr - mp[e]) * one_minus_b1;
+      vp[e] = vp[e] * b2 + (one_minus_b2 * gr) * gr;
+      const float denom = sqrtf(vp[e]) / bc2_sqrt + eps;
+      pp[e] = pp[e] + (neg_step_size * mp[e]) / denom;
+    }
+    *reinterpret_cast<float4*>(p + base) = pv;
+    *reinterpret_cast<float4*>(m + base) = mv;
+    *reinterpret_cast<float4*>(v + base) = vv;
+  } else {
+    for (int64_t e = base; e < count; ++e) {
+      const float gr = g[e] * grad_scale;
+      m[e] = m[e] + (gr - m[e]) * one_minus_b1;
+      v[e] = v[e] * b2 + (one_minus_b2 * gr) * gr;
+      const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
+      p[e] = p[e] + (neg_step_size * m[e]) / denom;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- sampler
+// Keyed bijection of [0, range): a 4-round Feistel network on the smallest even-width bit
+// field that covers `range`, with cycle walking for values that fall outside.  One key =
+// one shuffle of the data set (what DataLoader(shuffle=True) draws per epoch).
+__device__ __forceinline__ uint32_t mix32(uint32_t x, uint32_t k) {
+  x ^= k;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ uint64_t feistel(uint64_t v, int half_bits, uint64_t key) {
+  const uint64_t half_mask = (1ull << half_bits) - 1;
+  uint32_t left = (uint32_t)(v >> half_bits), right = (uint32_t)(v & half_mask);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t k = (uint32_t)(key >> (16 * r)) ^ (0x9e3779b9u * (r + 1));
+    const uint32_t f = mix32(right, k) & (uint32_t)half_mask;
+    const uint32_t nl = right;
+    right = left ^ f;
+    left = nl;
+  }
+  return ((uint64_t)left << half_bits) | right;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(uint64_t key, int64_t first, int64_t lo,
+                                                     int64_t range, int half_bits, int64_t n,
+                                                     int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t v = (uint64_t)((first + i) % range);
+  do {
+    v = feistel(v, half_bits, key);
+  } while (v >= (uint64_t)range);  // cycle walking: the field is < 4x range, so ~1-4 rounds
+  out[i] = lo + (int64_t)v;
+}
+
+struct ShapeTab {
+  int64_t shape[MRI_MAX_DIM];
+  int64_t axis_offset[MRI_MAX_DIM];
+};
+
+__global__ __launch_bounds__(256) void gather_batch_kernel(const int64_t* __restrict__ idx,
+                                                           int64_t n, int dim, ShapeTab tab,
+                                                           const float* __restrict__ axes,
+                                                           const float* __restrict__ volume,
+                                                           float* __restrict__ coords,
+                                                           float* __restrict__ target) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t flat = idx[i];
+  if (target) target[i] = volume[flat];
+  int64_t rest = flat;
+  for (int d = dim - 1; d >= 0; --d) {  // C order: last axis fastest (datamodules.py:162-163)
+    const int64_t pos = rest % tab.shape[d];
+    rest /= tab.shape[d];
+    coords[i * dim + d] = axes[tab.axis_offset[d] + pos];
+  }
+}
+
+}  // namespace
+}  // namespace mri
+
+using namespace mri;
+
+extern "C" const char* mri_version(void) { return "mri_inr 0.1.0 gfx950"; }
+extern "C" const char* mri_last_error(void) { return error_buffer(); }
+
+extern "C" int mri_set_option(const char* name, int32_t value) {
+  MRI_REQUIRE(name != nullptr, "option name is NULL");
+  if (!strcmp(name, "xcd_affinity")) {
+    options().xcd_affinity = value != 0;
+  } else if (!strcmp(name, "bwd_lds_max_parts")) {
+    options().bwd_lds_max_parts = value;
+  } else {
+    return fail(MRI_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+  }
+  return MRI_OK;
+}
+
+extern "C" int mri_mse_loss(const float* pred, const float* target, int64_t count,
+                            float grad_divisor, float* loss_out, float* d_pred, void* stream) {
+  MRI_REQUIRE(count >= 0, "negative count");
+  MRI_REQUIRE(grad_divisor > 0.f, "grad_divisor must be positive");
+  if (count == 0) return MRI_OK;
+  MRI_REQUIRE(pred && target && loss_out, "NULL device pointer");
+  const int blocks = (int)std::min<int64_t>(ceil_div(count, 256), 2048);
+  const float inv = (float)(1.0 / (double)count);
+  const float gs = (float)(2.0 / ((double)count * (double)grad_divisor));
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred,
+                     target, count, inv, gs, loss_out, d_pred);
+  return check_launch("mse_loss_kernel");
+}
+
+extern "C" int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             int64_t count, double lr, double beta1, double beta2,
+                             double eps, int32_t step, float grad_scale, void* stream) {
+  MRI_REQUIRE(count >= 0 && step >= 1, "bad count/step");
+  if (count == 0) return MRI_OK;
+  MRI_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL device pointer");
+  MRI_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) &
+               15) == 0,
+              "Adam buffers must be 16-byte aligned");
+  // scalar prefactors in double, as torch computes them on the host
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float neg_step_size = (float)(-(lr / bc1));
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const int64_t blocks = ceil_div(ceil_div(count, 4), 256);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     param, grad, exp_avg, exp_avg_sq, count, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), neg_step_size, bc2_sqrt, (float)eps, grad_scale);
+  return check_launch("adam_kernel");
+}
+
+extern "C" int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int64_t hi,
+                                  int64_t n, int64_t* idx_out, void* stream) {
+  MRI_REQUIRE(hi > lo && first >= 0 && n >= 0, "bad range [%lld, %lld)", (long long)lo,
+              (long long)hi);
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(idx_out, "NULL device pointer");
+  const int64_t range = hi - lo;
+  int bits = 2;
+  while ((1ll << bits) < range) ++bits;
+  if (bits & 1) ++bits;
+  MRI_REQUIRE(bits <= 62, "range too large");
+  // scramble the user seed so that nearby seeds give unrelated keys
+  uint64_t key = seed + 0x9E3779B97F4A7C15ull;
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  key ^= key >> 31;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, key, first, lo, range, bits / 2, n, idx_out);
+  return check_launch("sample_kernel");
+}
+
+extern "C" int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* shape,
+                                const float* axes, const int64_t* axis_offset,
+                                const float* volume, float* coords_out, float* target_out,
+                                void* stream) {
+  MRI_REQUIRE(n >= 0 && dim >= 1 && dim <= MRI_MAX_DIM, "bad n/dim");
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(idx && shape && axes && axis_offset && coords_out, "NULL pointer");
+  MRI_REQUIRE(!target_out || volume, "target_out needs a volume");
+  ShapeTab tab{};
+  for (int d = 0; d < dim; ++d) {
+    MRI_REQUIRE(shape[d] >= 1, "shape[%d] < 1", d);
+    tab.shape[d] = shape[d];
+    tab.axis_offset[d] = axis_offset[d];
+  }
+  hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, idx, n, (int)dim, tab, axes, volume, coords_out,
+                     target_out);
+  return check_launch("gather_batch_kernel");
+}

@@ -1,0 +1,177 @@
+"""Coordinate-batch producer with the reference's `MriImage` / `MriDataModule` surface.
+
+Mirrors reference `datamodules.py`: `MriImage` (datamodules.py:123-172) holds
+coords = meshgrid(linspace(0,1,s_d), 'ij') flattened C-order and pixels min-max normalised;
+`MriDataModule` (datamodules.py:175-252) hands out a shuffled train loader, an ordered test
+loader and a dense-grid `upsampling` loader.
+
+MI355X-first: the reference's real wall-clock limiter is the per-sample `__getitem__` +
+collate DataLoader.  Here the normalised volume lives in HBM and each batch
+is generated ON DEVICE by two kernels (csrc/train_ops.hip): a keyed permutation of the voxel
+range (a without-replacement shuffle, one key per epoch) and a gather that turns flat voxel
+indices into (coords, targets) through per-axis `torch.linspace` tables built on the host
+(so coordinates equal the reference's bit for bit, SURVEY.md section 7 hard part 6).
+"""
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import nifti, ops, parallel
+
+# Synthetic phantom of SURVEY.md 8(d) (amplitude, cx, cy, cz, sigma), frozen constants.
+PHANTOM_BLOBS = (
+    (0.914671, 0.705558, 0.440001, 0.208670, 0.167284),
+    (0.429870, 0.424467, 0.387700, 0.165612, 0.108726),
+    (0.944630, 0.773307, 0.166709, 0.735074, 0.175188),
+    (0.962596, 0.471719, 0.178302, 0.719093, 0.185785),
+    (0.912156, 0.693448, 0.651990, 0.195792, 0.077915),
+    (0.381020, 0.590153, 0.840326, 0.689920, 0.083039),
+    (0.435612, 0.299856, 0.210111, 0.831542, 0.050020),
+    (0.539216, 0.668344, 0.835137, 0.700320, 0.054043),
+    (0.647054, 0.243490, 0.233573, 0.305336, 0.168622),
+    (0.928860, 0.588131, 0.640457, 0.688756, 0.073182),
+    (0.304521, 0.433649, 0.395709, 0.780849, 0.044156),
+    (0.459188, 0.214497, 0.293642, 0.376995, 0.179894),
+)
+
+
+def phantom_volume(shape: Sequence[int], device="cuda") -> torch.Tensor:
+    """Analytic 3-D test volume (12 Gaussian blobs + a sinusoid), min-max normalised to
+    [0, 1] float32, evaluated at linspace(0,1,s) voxel centres in float64 on `device`."""
+    ax = [torch.linspace(0.0, 1.0, s, dtype=torch.float64, device=device) for s in shape]
+    x, y, z = torch.meshgrid(*ax, indexing="ij")
+    v = 0.05 * torch.sin(2.0 * math.pi * (7.0 * x + 11.0 * y + 13.0 * z))
+    for a, cx, cy, cz, s in PHANTOM_BLOBS:
+        v = v + a * torch.exp(-((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) / (2.0 * s * s))
+    v = (v - v.min()) / (v.max() - v.min())
+    return v.to(torch.float32)
+
+
+class MriImage:
+    """Dataset for implicit-representation training: coordinates in x, intensity in y."""
+
+    def __init__(self, config=None, image_path: Optional[str] = None, norm_siren: bool = False,
+                 volume=None, device=None, *args, **kwargs):
+        if volume is None:
+            path = image_path if image_path else config.image_path
+            volume = nifti.load(path)
+        self.device = torch.device(device if device is not None else "cuda")
+        vol = torch.as_tensor(volume, dtype=torch.float32).to(self.device)
+        self.shape = tuple(int(s) for s in vol.shape)
+        self.dim_in = len(self.shape)
+        self.norm_siren = norm_siren
+        lo = -1.0 if norm_siren else 0.0
+        # axes built with torch.linspace on the CPU, as the reference does, then uploaded
+        axes = [torch.linspace(lo, 1.0, s) for s in self.shape]
+        self.axis_offset = [0]
+        for a in axes[:-1]:
+            self.axis_offset.append(self.axis_offset[-1] + a.numel())
+        self.axes = torch.cat(axes).to(self.device)
+        pix = vol.flatten()
+        pix = (pix - torch.min(pix)) / (torch.max(pix) - torch.min(pix))
+        if norm_siren:
+            pix = pix * 2 - 1
+        self.pixels = pix.unsqueeze(-1).contiguous()  # (N, 1), C-order flatten
+
+    def __len__(self):
+        return self.pixels.shape[0]
+
+    def batch(self, idx: torch.Tensor, coords=None, target=None):
+        """(coords (n, D), pixels (n, 1)) for flat voxel indices `idx` (int64 on device)."""
+        return ops.gather_batch(idx, self.shape, self.axes, self.axis_offset, self.pixels,
+                                coords, target)
+
+    def __getitem__(self, idx):
+        single = isinstance(idx, int)
+        t = torch.as_tensor([idx] if single else idx, dtype=torch.int64, device=self.device)
+        c, p = self.batch(t.reshape(-1))
+        return (c[0], p[0]) if single else (c, p)
+
+    @property
+    def coords(self) -> torch.Tensor:
+        """All coordinates (N, D), generated on demand."""
+        idx = torch.arange(len(self), device=self.device)
+        return self.batch(idx)[0]
+
+
+class DeviceLoader:
+    """Iterable of on-device (coords, targets) batches over a voxel range [lo, hi)."""
+
+    def __init__(self, dataset: MriImage, batch_size: int, shuffle: bool, lo: int = 0,
+                 hi: Optional[int] = None, seed: int = 1337, drop_last: bool = False):
+        self.ds, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
+        self.lo, self.hi = lo, len(dataset) if hi is None else hi
+        self.seed, self.epoch, self.drop_last = seed, 0, drop_last
+
+    def __len__(self):
+        n = self.hi - self.lo
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def indices(self, first: int, n: int) -> torch.Tensor:
+        if self.shuffle:
+            return ops.sample_indices(self.seed + 7919 * self.epoch, first, self.lo, self.hi, n,
+                                      device=self.ds.device)
+        return torch.arange(self.lo + first, self.lo + first + n, device=self.ds.device)
+
+    def __iter__(self):
+        total = self.hi - self.lo
+        for b in range(len(self)):
+            first = b * self.batch_size
+            n = min(self.batch_size, total - first)
+            yield self.ds.batch(self.indices(first, n))
+        self.epoch += 1
+
+
+class GridLoader:
+    """Ordered batches of dense-grid coordinates (no targets: zeros, as the reference's
+    mock loader yields -- datamodules.py:229-252)."""
+
+    def __init__(self, shape, batch_size, norm_siren=False, device="cuda"):
+        self.grid = MriImage(volume=np.zeros(shape, dtype=np.float32), norm_siren=norm_siren,
+                             device=device)
+        self.grid.pixels.zero_()
+        self.loader = DeviceLoader(self.grid, batch_size, shuffle=False)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        return iter(self.loader)
+
+
+class MriDataModule:
+    """Takes ONE MRI image and returns coords and pixels (no train/val/test split)."""
+
+    def __init__(self, config=None, volume=None, norm_siren: bool = False, *args, **kwargs):
+        self.config = config
+        self.volume = volume
+        self.norm_siren = norm_siren
+        self.dataset = self.train_ds = self.val_ds = self.test_ds = None
+
+    def prepare_data(self) -> None:
+        self.dataset = MriImage(config=self.config, volume=self.volume,
+                                norm_siren=self.norm_siren)
+        self.train_ds = self.test_ds = self.val_ds = self.dataset
+
+    def setup(self, stage=None):
+        pass
+
+    def train_dataloader(self, rank: int = 0, world: int = 1) -> DeviceLoader:
+        """Shuffled loader over this rank's slab of the volume (whole volume for world 1)."""
+        lo, hi = parallel.voxel_range(self.train_ds.shape, rank, world)
+        return DeviceLoader(self.train_ds, self.config.batch_size, shuffle=True, lo=lo, hi=hi,
+                            seed=getattr(self.config, "seed", 1337) + rank)
+
+    def val_dataloader(self) -> DeviceLoader:
+        return DeviceLoader(self.val_ds, self.config.batch_size, shuffle=False)
+
+    def test_dataloader(self) -> DeviceLoader:
+        return DeviceLoader(self.test_ds, self.config.batch_size, shuffle=False)
+
+    def upsampling(self, shape, batch_size, norm_siren: bool = False) -> GridLoader:
+        return GridLoader(shape, batch_size, norm_siren)

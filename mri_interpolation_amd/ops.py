@@ -1,0 +1,297 @@
+"""Tensor-level wrappers over the C ABI (include/mri_inr.h) and the autograd glue.
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below
+is a call into libmri_inr.so.  CPU tensors are rejected -- there is no fallback.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_IDENTITY, ACT_RELU, ACT_SINE, DERIV_MUL, DERIV_NONE,  # noqa: F401
+                   DERIV_RELU_MASK, GridDesc)
+
+
+# --------------------------------------------------------------------------- helpers
+def _gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mri_interpolation_amd: the hot path runs on MI355X only; got a "
+                               f"{t.device} tensor (no CPU fallback exists)")
+        if t.dtype != torch.float32 and t.dtype != torch.int64:
+            raise TypeError(f"expected float32/int64 tensor, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """2-D view with unit column stride (copies only if needed)."""
+    if t.dim() != 2:
+        t = t.reshape(-1, t.shape[-1])
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def make_grid_desc(dim: int, resolutions: Sequence[Sequence[float]], sizes: Sequence[int],
+                   n_features: int) -> GridDesc:
+    """Host descriptor from per-level per-axis resolutions and table sizes."""
+    if not (1 <= dim <= _lib.MAX_DIM):
+        raise ValueError(f"HashGrid only supports 1..{_lib.MAX_DIM}-D inputs")
+    if not (1 <= len(sizes) <= _lib.MAX_LEVELS):
+        raise ValueError(f"n_levels must be in 1..{_lib.MAX_LEVELS}")
+    g = GridDesc()
+    g.dim, g.n_levels, g.n_features = dim, len(sizes), n_features
+    off = 0
+    for l, (res, size) in enumerate(zip(resolutions, sizes)):
+        for d in range(dim):
+            g.resolution[l][d] = float(res[d])
+        g.table_size[l] = int(size)
+        g.table_offset[l] = off
+        off += int(size)
+    return g
+
+
+def grid_rows(desc: GridDesc) -> int:
+    return sum(desc.table_size[l] for l in range(desc.n_levels))
+
+
+def _enc_strides(desc: GridDesc, n: int, feature_major: bool):
+    f = desc.n_features
+    if feature_major:  # (L*F, n)
+        return f * n, 1, n
+    return f, desc.n_levels * f, 1  # reference layout (n, L*F)
+
+
+# --------------------------------------------------------------------------- hash grid
+def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
+                     out: Optional[torch.Tensor] = None, feature_major: bool = False):
+    _gpu(x, table, out)
+    x = _rowmajor(x).contiguous()
+    n, width = x.shape[0], desc.n_levels * desc.n_features
+    if x.shape[1] != desc.dim:
+        raise ValueError(f"x has {x.shape[1]} columns, encoder expects {desc.dim}")
+    if out is None:
+        out = torch.empty((width, n) if feature_major else (n, width), device=x.device,
+                          dtype=torch.float32)
+    sl, sr, sf = _enc_strides(desc, n, feature_major)
+    _lib.call("mri_hashgrid_forward", C.byref(desc), _ptr(x), n, _ptr(table), _ptr(out), sl, sr,
+              sf, _stream())
+    return out
+
+
+def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
+                      d_table: torch.Tensor, feature_major: bool = False, method: int = 0):
+    """d_table += scatter of d_out (accumulates)."""
+    _gpu(x, d_out, d_table)
+    x = _rowmajor(x).contiguous()
+    n = x.shape[0]
+    if not d_out.is_contiguous():
+        d_out = d_out.contiguous()
+    sl, sr, sf = _enc_strides(desc, n, feature_major)
+    _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
+              _ptr(d_table), method, _stream())
+    return d_table
+
+
+class HashGridFunction(torch.autograd.Function):
+    """Autograd node for the encoder: gradient flows to the table only (the reference's
+    coordinates never require grad; encoding.py:113 keeps that path but nothing uses it)."""
+
+    @staticmethod
+    def forward(ctx, x, table, desc):
+        ctx.desc = desc
+        ctx.save_for_backward(x)
+        ctx.table_shape = table.shape
+        return hashgrid_forward(desc, x, table)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        d_table = torch.zeros(ctx.table_shape, device=d_out.device, dtype=torch.float32)
+        hashgrid_backward(ctx.desc, x, d_out.contiguous(), d_table)
+        return None, d_table, None
+
+
+# --------------------------------------------------------------------------- linear layers
+def linear_forward(x, weight, bias, activation=ACT_IDENTITY, w0=1.0, out=None, deriv=None,
+                   x_feature_major=False):
+    """y = act(w0 * (x W^T + b)); x is (M, K), or (K, M) when x_feature_major."""
+    _gpu(x, weight, bias, out, deriv)
+    n, k = weight.shape
+    if x_feature_major:
+        if not x.is_contiguous():
+            x = x.contiguous()
+        m, xrs, xcs = x.shape[1], 1, x.shape[1]
+        if x.shape[0] != k:
+            raise ValueError(f"x has {x.shape[0]} features, weight expects {k}")
+    else:
+        x = _rowmajor(x)
+        m, xrs, xcs = x.shape[0], x.stride(0), 1
+        if x.shape[1] != k:
+            raise ValueError(f"x has {x.shape[1]} features, weight expects {k}")
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    if out is None:
+        out = torch.empty((m, n), device=x.device, dtype=torch.float32)
+    _lib.call("mri_linear_forward", _ptr(x), xrs, xcs, _ptr(weight), _ptr(bias), m, n, k,
+              activation, float(w0), _ptr(out), out.stride(0), _ptr(deriv),
+              deriv.stride(0) if deriv is not None else 0, _stream())
+    return out
+
+
+def linear_backward_data(dy, weight, deriv_mode=DERIV_NONE, deriv=None, dx=None,
+                         dx_feature_major=False):
+    _gpu(dy, weight, deriv, dx)
+    dy = _rowmajor(dy)
+    n, k = weight.shape
+    m = dy.shape[0]
+    if not weight.is_contiguous():
+        weight = weight.contiguous()
+    if dx is None:
+        dx = torch.empty((k, m) if dx_feature_major else (m, k), device=dy.device,
+                         dtype=torch.float32)
+    drs, dcs = (1, dx.stride(0)) if dx_feature_major else (dx.stride(0), 1)
+    _lib.call("mri_linear_backward_data", _ptr(dy), dy.stride(0), _ptr(weight), m, n, k,
+              deriv_mode, _ptr(deriv), deriv.stride(0) if deriv is not None else 0, _ptr(dx),
+              drs, dcs, _stream())
+    return dx
+
+
+def linear_backward_weight(dy, x, d_weight, d_bias=None, x_feature_major=False):
+    """d_weight += dy^T x, d_bias += colsum(dy)."""
+    _gpu(dy, x, d_weight, d_bias)
+    dy = _rowmajor(dy)
+    n, k = d_weight.shape
+    m = dy.shape[0]
+    if x_feature_major:
+        if not x.is_contiguous():
+            x = x.contiguous()
+        xrs, xcs = 1, x.shape[1]
+    else:
+        x = _rowmajor(x)
+        xrs, xcs = x.stride(0), 1
+    _lib.call("mri_linear_backward_weight", _ptr(dy), dy.stride(0), _ptr(x), xrs, xcs, m, n, k,
+              _ptr(d_weight), _ptr(d_bias), _stream())
+
+
+def apply_deriv(dy, deriv_mode, deriv):
+    _gpu(dy, deriv)
+    if deriv_mode == DERIV_NONE:
+        return dy
+    _lib.call("mri_apply_deriv", _ptr(dy), dy.stride(0), deriv_mode, _ptr(deriv),
+              deriv.stride(0), dy.shape[0], dy.shape[1], _stream())
+    return dy
+
+
+def deriv_mode_for(activation: int) -> int:
+    return {ACT_IDENTITY: DERIV_NONE, ACT_RELU: DERIV_RELU_MASK, ACT_SINE: DERIV_MUL,
+            ACT_GELU: DERIV_MUL}[activation]
+
+
+class LinearActFunction(torch.autograd.Function):
+    """y = act(w0 (x W^T + b)) as one MFMA kernel, with its three backward GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, activation, w0):
+        lead = x.shape[:-1]
+        x2 = _rowmajor(x)
+        need_deriv = activation in (ACT_SINE, ACT_GELU)
+        deriv = torch.empty((x2.shape[0], weight.shape[0]), device=x.device,
+                            dtype=torch.float32) if need_deriv else None
+        y = linear_forward(x2, weight, bias, activation, w0, deriv=deriv)
+        ctx.activation = activation
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, deriv if need_deriv else y)
+        ctx.lead = lead
+        return y.reshape(*lead, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, g = ctx.saved_tensors
+        dz = dy.reshape(-1, weight.shape[0]).contiguous()
+        mode = deriv_mode_for(ctx.activation)
+        if mode != DERIV_NONE:
+            dz = apply_deriv(dz.clone() if dz.data_ptr() == dy.data_ptr() else dz, mode, g)
+        dx = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_backward_data(dz, weight).reshape(*ctx.lead, weight.shape[1])
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            d_w = torch.zeros_like(weight)
+            d_b = torch.zeros(weight.shape[0], device=dy.device) if ctx.has_bias else None
+            linear_backward_weight(dz, x2, d_w, d_b)
+        return dx, d_w, d_b, None, None
+
+
+def linear_act(x, weight, bias, activation=ACT_IDENTITY, w0=1.0):
+    return LinearActFunction.apply(x, weight, bias, activation, w0)
+
+
+# --------------------------------------------------------------------------- loss / optimiser
+def mse_loss(pred, target, loss_out, d_pred=None, grad_divisor: float = 1.0):
+    """loss_out[0] += mean((pred - target)^2); d_pred = 2 (pred - target) / (N * divisor)."""
+    _gpu(pred, target, loss_out, d_pred)
+    if not (pred.is_contiguous() and target.is_contiguous()):
+        raise ValueError("mse_loss needs contiguous tensors")
+    if pred.numel() != target.numel():
+        raise ValueError("pred and target differ in size")
+    _lib.call("mri_mse_loss", _ptr(pred), _ptr(target), pred.numel(), float(grad_divisor),
+              _ptr(loss_out), _ptr(d_pred), _stream())
+    return loss_out
+
+
+class MSELossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss = torch.zeros(1, device=pred.device, dtype=torch.float32)
+        d_pred = torch.empty_like(pred, memory_format=torch.contiguous_format)
+        mse_loss(pred.contiguous(), target.contiguous(), loss, d_pred)
+        ctx.save_for_backward(d_pred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * g, None
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
+              grad_scale: float = 1.0):
+    _gpu(param, grad, exp_avg, exp_avg_sq)
+    _lib.call("mri_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+              param.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
+              float(grad_scale), _stream())
+
+
+# --------------------------------------------------------------------------- batch producer
+def sample_indices(seed: int, first: int, lo: int, hi: int, n: int, out=None, device="cuda"):
+    if out is None:
+        out = torch.empty(n, device=device, dtype=torch.int64)
+    _gpu(out)
+    _lib.call("mri_sample_indices", C.c_uint64(seed & (2 ** 64 - 1)), first, lo, hi, n, _ptr(out),
+              _stream())
+    return out
+
+
+def gather_batch(idx, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],
+                 volume: Optional[torch.Tensor], coords=None, target=None):
+    _gpu(idx, axes, volume, coords, target)
+    n, dim = idx.numel(), len(shape)
+    if coords is None:
+        coords = torch.empty((n, dim), device=idx.device, dtype=torch.float32)
+    if target is None and volume is not None:
+        target = torch.empty((n, 1), device=idx.device, dtype=torch.float32)
+    shp = (C.c_int64 * dim)(*[int(s) for s in shape])
+    off = (C.c_int64 * dim)(*[int(o) for o in axis_offset])
+    _lib.call("mri_gather_batch", _ptr(idx), n, dim, shp, _ptr(axes), off, _ptr(volume),
+              _ptr(coords), _ptr(target), _stream())
+    return coords, target

@@ -1,0 +1,102 @@
+"""Adam over ONE flat parameter buffer, stepped by the fused gfx950 kernel.
+
+Same update rule, defaults and call surface as `torch.optim.Adam(params, lr)` which the
+reference builds in `configure_optimizers` (reference models.py:68-70): betas (0.9, 0.999),
+eps 1e-8, no weight decay, no amsgrad.
+
+MI355X-first: every parameter (hash tables + MLP weights) is re-pointed into one contiguous
+buffer, gradients into a second one, so that a step is ONE kernel launch streaming
+28 B/parameter, and the data-parallel gradient reduction is ONE RCCL collective.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import ops
+
+_ALIGN = 4  # floats (16 B): keeps every parameter's base aligned for float4 access
+
+
+class FlatBuffers:
+    """Parameters, gradients and Adam moments of a model as four flat float32 tensors."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("mri_interpolation_amd.optim: parameters must live on the GPU "
+                               "(move the model with .cuda() first; there is no CPU fallback)")
+        self.offsets, total = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise TypeError("all parameters must be float32 on one device")
+            self.offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.param = torch.zeros(total, device=dev)
+        self.grad = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                n = p.numel()
+                self.param[off:off + n].copy_(p.detach().reshape(-1))
+                old_grad = p.grad
+                p.data = self.param[off:off + n].view(p.shape)
+                if old_grad is not None:
+                    self.grad[off:off + n].copy_(old_grad.reshape(-1))
+                p.grad = self.grad[off:off + n].view(p.shape)
+
+    def grad_view(self, p: torch.nn.Parameter) -> torch.Tensor:
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        off = self.offsets[i]
+        return self.grad[off:off + p.numel()].view(p.shape)
+
+
+class Adam:
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self._params = [p for p in params]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.flat: Optional[FlatBuffers] = None
+        self.grad_scale = 1.0  # 1/world_size after an all-reduce(sum)
+        self.param_groups = [dict(params=self._params, lr=lr, betas=betas, eps=eps)]
+
+    def flatten(self) -> FlatBuffers:
+        if self.flat is None:
+            self.flat = FlatBuffers(self._params)
+        return self.flat
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self.flat is not None:
+            self.flat.grad.zero_()
+        else:
+            for p in self._params:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        flat = self.flatten()
+        for p, off in zip(flat.params, flat.offsets):
+            # autograd may have replaced the view (first backward before flatten()):
+            g = p.grad
+            if g is not None and g.data_ptr() != flat.grad.data_ptr() + 4 * off:
+                flat.grad[off:off + p.numel()].copy_(g.reshape(-1))
+                p.grad = flat.grad[off:off + p.numel()].view(p.shape)
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        ops.adam_step(flat.param, flat.grad, flat.exp_avg, flat.exp_avg_sq, lr, self.betas[0],
+                      self.betas[1], self.eps, self.step_count, self.grad_scale)
+
+    def state_dict(self):
+        f = self.flatten()
+        return dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
+                    exp_avg=f.exp_avg.clone(), exp_avg_sq=f.exp_avg_sq.clone())
+
+    def load_state_dict(self, sd):
+        f = self.flatten()
+        self.step_count = int(sd["step"])
+        f.exp_avg.copy_(sd["exp_avg"])
+        f.exp_avg_sq.copy_(sd["exp_avg_sq"])

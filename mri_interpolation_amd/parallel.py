@@ -1,0 +1,93 @@
+"""Data parallelism over the 8 GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code.  The path shards naturally:
+coordinates are independent, all parameters are shared, so each rank trains on its own
+slab of the volume (contiguous range of the slowest axis, equal local batch) and one
+gradient reduction per step makes the update identical on every rank (mean of equal-sized
+local means = global mean, i.e. DDP semantics).
+
+Everything here is host logic over `torch.distributed`; it works with the `gloo` backend
+on CPU tensors too, which is how the N > 1 path is tested without GPUs.
+"""
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Join the process group described by the environment; no-op for a single process."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def slab_range(n_slow: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of the slowest axis owned by `rank`; remainders go to the first ranks."""
+    if world > n_slow:
+        raise ValueError(f"cannot cut {n_slow} slices into {world} slabs; shard another axis "
+                         "or use flat_range()")
+    base, rem = divmod(n_slow, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def flat_range(n_voxels: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous flat-index range per rank (for volumes whose slow axis is shorter than
+    the world size, e.g. the sample's 6 z-slices on 8 GPUs -- SURVEY.md 8(d) cfg 5)."""
+    base, rem = divmod(n_voxels, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def voxel_range(shape, rank: int, world: int) -> Tuple[int, int]:
+    """Flat C-order voxel range of this rank's slab (slowest axis), falling back to a flat
+    split when the slowest axis has fewer slices than ranks."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    if world == 1:
+        return 0, n
+    if shape[0] >= world:
+        lo, hi = slab_range(int(shape[0]), rank, world)
+        per_slice = n // int(shape[0])
+        return lo * per_slice, hi * per_slice
+    return flat_range(n, rank, world)
+
+
+def all_reduce_sum(flat: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks of one flat buffer: ONE collective per step for all
+    gradients (tables + MLP).  Gradients are pre-divided by world_size in the loss kernel."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def all_reduce_max(value: float, device) -> float:
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,282 @@
+"""Training / prediction loop for the coordinate networks (stands in for `pl.Trainer`).
+
+The reference drives its models through `pytorch_lightning.Trainer.fit / .predict`
+(reference launcher.py:156-165,179,213): per batch `training_step` -> `loss.backward()` ->
+`Adam.step()`.  `Trainer` keeps that protocol.  For the model families of
+BASELINE.json (SirenNet, BaseMLP, HashMLP with the fused tiny-MLP decoder) the step is
+compiled into an explicit kernel chain, `FusedStep`, with no autograd graph:
+
+    [hashgrid_fwd] -> linear_fwd x n -> mse_loss -> (linear_bwd_weight, linear_bwd_data) x n
+    -> [hashgrid_bwd] -> [RCCL all-reduce of ONE flat gradient buffer] -> adam (ONE launch)
+
+All activations live in workspaces allocated once per batch size; the encoder output and its
+gradient use the feature-major layout so the hash kernels store/load coalesced.
+Other models (e.g. the BatchNorm decoder) run `training_step` + autograd, op by op.
+"""
+import contextlib
+import time
+from typing import Dict, List, Optional
+
+import torch
+
+from . import models, ops, optim, parallel
+
+
+class _Layer:
+    def __init__(self, weight, bias, activation, w0):
+        self.weight, self.bias, self.activation, self.w0 = weight, bias, activation, w0
+
+
+def fusable_layers(model) -> Optional[tuple]:
+    """(encoder or None, [_Layer, ...]) if the model is a plain chain of fused layers."""
+    enc, layers = None, []
+    if isinstance(model, models.SirenNet):
+        for l in list(model.layers) + [model.last_layer]:
+            if l._code is None:
+                return None
+            layers.append(_Layer(l.weight, l.bias, l._code[0], l._code[1]))
+        return enc, layers
+    if isinstance(model, models.HashMLP):
+        enc = model.encoder
+        for block in model.decoder:
+            lin, norm, act, drop = block[0], block[1], block[2], block[3]
+            if not isinstance(norm, models._Fused):
+                return None
+            if not isinstance(act, (models._Fused, torch.nn.Identity)):
+                return None
+            if drop.p != 0.0:
+                return None
+            layers.append(_Layer(lin.weight, lin.bias, lin.activation_code, lin.w0))
+        return enc, layers
+    if isinstance(model, models.BaseMLP) and isinstance(getattr(model, "layers", None),
+                                                        torch.nn.Sequential):
+        for m in model.layers:
+            if isinstance(m, models.FusedLinear):
+                layers.append(_Layer(m.weight, m.bias, m.activation_code, m.w0))
+            elif not isinstance(m, models._Fused):
+                return None
+        return enc, layers
+    return None
+
+
+class FusedStep:
+    """Explicit forward / backward kernel chain over preallocated workspaces."""
+
+    def __init__(self, model, optimizer: optim.Adam, world: int = 1):
+        plan = fusable_layers(model)
+        if plan is None:
+            raise ValueError("model is not a fusable chain")
+        self.encoder, self.layers = plan
+        self.opt = optimizer
+        self.flat = optimizer.flatten()
+        self.world = world
+        self.bwd_method = 0
+        self.phase_events: Optional[Dict[str, list]] = None  # bench.py: per-phase HIP events
+        self._ws = {}
+        self.loss = torch.zeros(1, device=self.flat.param.device)
+        self._grads = [(self.flat.grad_view(l.weight),
+                        self.flat.grad_view(l.bias) if l.bias is not None else None)
+                       for l in self.layers]
+        self._table_grad = self.flat.grad_view(self.encoder.table) if self.encoder else None
+
+    @contextlib.contextmanager
+    def _phase(self, name: str):
+        """Bracket a phase with HIP events on the launch stream when timing is enabled."""
+        if self.phase_events is None:
+            yield
+            return
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        yield
+        stop.record()
+        self.phase_events.setdefault(name, []).append((start, stop))
+
+    def phase_ms(self) -> Dict[str, float]:
+        """Mean milliseconds per step of every recorded phase (synchronises)."""
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v)
+                for k, v in (self.phase_events or {}).items()}
+
+    def _workspace(self, n: int, train: bool):
+        key = (n, train)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.flat.param.device
+            new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+            ws = dict(y=[new(n, l.weight.shape[0]) for l in self.layers])
+            if self.encoder is not None:
+                ws["enc"] = new(self.encoder.output_dim, n)
+            if train:
+                ws["deriv"] = [new(n, l.weight.shape[0])
+                               if l.activation in (ops.ACT_SINE, ops.ACT_GELU) else None
+                               for l in self.layers]
+                ws["dz"] = [new(n, l.weight.shape[0]) for l in self.layers]
+                if self.encoder is not None:
+                    ws["d_enc"] = new(self.encoder.output_dim, n)
+            self._ws = {k: v for k, v in self._ws.items() if k[1] != train}  # keep one size
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, coords: torch.Tensor, train: bool = False):
+        n = coords.shape[0]
+        ws = self._workspace(n, train)
+        x, feature_major = coords, False
+        if self.encoder is not None:
+            with self._phase("hashgrid_fwd"):
+                x = ops.hashgrid_forward(self.encoder.desc, coords, self.encoder.table.data,
+                                         out=ws["enc"], feature_major=True)
+            feature_major = True
+        with self._phase("mlp_fwd"):
+            for i, l in enumerate(self.layers):
+                deriv = ws["deriv"][i] if train else None
+                x = ops.linear_forward(x, l.weight.data,
+                                       None if l.bias is None else l.bias.data, l.activation,
+                                       l.w0, out=ws["y"][i], deriv=deriv,
+                                       x_feature_major=feature_major)
+                feature_major = False
+        return x, ws
+
+    def _deriv_of(self, i, ws):
+        mode = ops.deriv_mode_for(self.layers[i].activation)
+        if mode == ops.DERIV_MUL:
+            return mode, ws["deriv"][i]
+        if mode == ops.DERIV_RELU_MASK:
+            return mode, ws["y"][i]
+        return mode, None
+
+    def backward(self, coords, target, ws):
+        """Gradients of mean squared error into the flat gradient buffer (zeroed here)."""
+        with self._phase("zero_grad"):
+            self.flat.grad.zero_()
+            self.loss.zero_()
+        last = len(self.layers) - 1
+        pred = ws["y"][last]
+        dz = ws["dz"][last]
+        with self._phase("loss"):
+            ops.mse_loss(pred, target, self.loss, dz, grad_divisor=float(self.world))
+            mode, g = self._deriv_of(last, ws)
+            ops.apply_deriv(dz, mode, g)
+        with self._phase("mlp_bwd"):
+            for i in range(last, -1, -1):
+                l = self.layers[i]
+                gw, gb = self._grads[i]
+                first_on_encoder = i == 0 and self.encoder is not None
+                x = ws["enc"] if first_on_encoder else (coords if i == 0 else ws["y"][i - 1])
+                ops.linear_backward_weight(dz, x, gw, gb, x_feature_major=first_on_encoder)
+                if i > 0:
+                    mode, g = self._deriv_of(i - 1, ws)
+                    dz = ops.linear_backward_data(dz, l.weight.data, mode, g,
+                                                  dx=ws["dz"][i - 1])
+                elif self.encoder is not None:
+                    ops.linear_backward_data(dz, l.weight.data, ops.DERIV_NONE, None,
+                                             dx=ws["d_enc"], dx_feature_major=True)
+        if self.encoder is not None:
+            with self._phase("hashgrid_bwd"):
+                ops.hashgrid_backward(self.encoder.desc, coords, ws["d_enc"], self._table_grad,
+                                      feature_major=True, method=self.bwd_method)
+
+    def train_step(self, coords, target) -> torch.Tensor:
+        """One optimisation step; returns the (device) loss scalar of this rank's batch."""
+        _, ws = self.forward(coords, train=True)
+        self.backward(coords, target, ws)
+        if self.world > 1:
+            with self._phase("all_reduce"):
+                parallel.all_reduce_sum(self.flat.grad)
+        with self._phase("adam"):
+            self.opt.step()
+        return self.loss
+
+
+class Trainer:
+    """fit / predict with the subset of `pl.Trainer` the reference launcher uses."""
+
+    def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
+                 precision: int = 32, log_every: int = 0, distributed: bool = True, **kwargs):
+        if precision != 32:
+            raise ValueError("the MI355X path is fp32 only (BASELINE parity is 1e-5 fp32)")
+        self.max_epochs, self.max_steps, self.log_every = max_epochs, max_steps, log_every
+        self.rank, self.world, _ = parallel.env_world() if distributed else (0, 1, 0)
+        self.global_step = 0
+        self.history: List[float] = []
+        self.throughput: List[float] = []
+        self.fused: Optional[FusedStep] = None
+
+    def _prepare(self, model):
+        if next(model.parameters()).device.type != "cuda":
+            model.cuda()
+        opt = getattr(model, "optimizer", None)
+        if not isinstance(opt, optim.Adam):
+            opt = model.configure_optimizers()
+            model.optimizer = opt
+        try:
+            self.fused = FusedStep(model, opt, self.world)
+        except ValueError:
+            self.fused = None
+            opt.flatten()
+        return opt
+
+    def fit(self, model, train_dataloaders):
+        opt = self._prepare(model)
+        model.train()
+        done = False
+        for epoch in range(self.max_epochs):
+            if hasattr(train_dataloaders, "set_epoch"):
+                train_dataloaders.set_epoch(epoch)
+            t0, seen = time.perf_counter(), 0
+            for batch_idx, (x, y) in enumerate(train_dataloaders):
+                if self.fused is not None:
+                    loss = self.fused.train_step(x, y)
+                else:
+                    opt.zero_grad()
+                    loss = model.training_step((x, y), batch_idx)
+                    if self.world > 1:
+                        loss = loss / self.world
+                    loss.backward()
+                    if self.world > 1:
+                        parallel.all_reduce_sum(opt.flatten().grad)
+                    opt.step()
+                self.global_step += 1
+                seen += x.shape[0]
+                if self.log_every and self.global_step % self.log_every == 0:
+                    self.history.append(float(loss))
+                    if self.rank == 0:
+                        print(f"epoch {epoch} step {self.global_step} loss {self.history[-1]:.6e}",
+                              flush=True)
+                if 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            torch.cuda.synchronize()
+            self.throughput.append(seen * self.world / max(time.perf_counter() - t0, 1e-9))
+            if done:
+                break
+        return model
+
+    @torch.no_grad()
+    def predict(self, model, dataloaders) -> List[torch.Tensor]:
+        """List of per-batch predictions, as `pl.Trainer.predict` returns."""
+        if next(model.parameters()).device.type != "cuda":
+            model.cuda()
+        model.eval()
+        fused = self.fused
+        if fused is None:
+            try:
+                fused = FusedStep(model, model.optimizer if hasattr(model, "optimizer")
+                                  else model.configure_optimizers(), 1)
+            except ValueError:
+                fused = None
+        out = []
+        for batch_idx, (x, y) in enumerate(dataloaders):
+            if fused is not None:
+                pred, _ = fused.forward(x, train=False)
+                out.append(pred.clone())
+            else:
+                out.append(model.predict_step((x, y), batch_idx))
+        return out
+
+
+def psnr(pred: torch.Tensor, target: torch.Tensor) -> float:
+    """10 log10(1 / MSE) for intensities in [0, 1] (what
+    skimage.metrics.peak_signal_noise_ratio computes for non-negative float images,
+    reference legacy_code/hash_experimentation.py:445-450)."""
+    mse = torch.mean((pred.double() - target.double()) ** 2)
+    return float(10.0 * torch.log10(1.0 / mse))
