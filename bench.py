@@ -69,7 +69,8 @@ def cpu_baseline(w, name):
     bounded sample of the same workload."""
     import torch
     from oracle import train as otrain
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-CPU share (os.cpu_count() reports the whole host)
+    cores = int(os.environ.get("MRI_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     b = 1 << 15 if w["model"] == "hash" else 1 << 14
     if w["model"] == "hash":

@@ -67,8 +67,8 @@ typedef struct mri_grid_desc {
 /* Library / build identification: "mri_inr <version> gfx950". */
 const char* mri_version(void);
 const char* mri_last_error(void);
-/* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n); results stay within
- * fp32 summation-order noise. */
+/* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level"
+ * n); results stay within fp32 summation-order noise. */
 int mri_set_option(const char* name, int32_t value);
 
 /* ---- hash-grid encoding --------------------------------------------------------------
@@ -91,11 +91,17 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  * the mul/sum backward (reference encoding.py:127-128).
  * d_table (sum T_l, F) is ACCUMULATED into (caller zeroes it).  d_out uses the same
  * three-stride addressing as `out` above.
- *   method 0 = choose per level; 1 = global float atomics; 2 = LDS-privatised owner-computes
+ *   method 0 = choose per level; 1 = global float atomics; 2 = LDS owner-computes scan with
+ *   64-bit fixed-point accumulation (bitwise reproducible gradients).
+ *   workspace: device scratch of at least mri_hashgrid_backward_workspace_bytes(grid, n)
+ *   bytes, 8-byte aligned, ZERO-INITIALISED by the caller once; every call leaves it zeroed
+ *   again, so it can be reused across steps without clearing.  May be NULL for method 1.
  */
+int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n);
 int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x, const float* d_out,
                           int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
-                          int64_t dout_feat_stride, float* d_table, int32_t method, void* stream);
+                          int64_t dout_feat_stride, float* d_table, int32_t method,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- fully connected layers (f32 MFMA) ------------------------------------------------
  * y = act(w0 * (x W^T + b))   with W (N, K) row-major as nn.Linear / SirenLayer store it.

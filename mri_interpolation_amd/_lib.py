@@ -38,7 +38,8 @@ _D = C.c_double
 SIGNATURES = {
     "mri_set_option": [C.c_char_p, _I32],
     "mri_hashgrid_forward": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _I64, _P],
-    "mri_hashgrid_backward": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32, _P],
+    "mri_hashgrid_backward": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32, _P,
+                              _I64, _P],
     "mri_linear_forward": [_P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _P, _I64, _P,
                            _I64, _P],
     "mri_linear_backward_data": [_P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _I64, _I64,
@@ -51,6 +52,7 @@ SIGNATURES = {
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
+INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64]}
 
 _lib = None
 
@@ -64,6 +66,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be in the process BEFORE this library is
+    # dlopen'ed, otherwise a second HIP runtime (the system one) gets loaded and kernels are
+    # launched on a runtime that owns no device context.
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError(
             f"{_LIB_PATH} is missing: build it with `python -m mri_interpolation_amd.build` "
@@ -76,6 +82,9 @@ def load():
     for name in STRING_GETTERS:
         getattr(lib, name).restype = C.c_char_p
         getattr(lib, name).argtypes = []
+    for name, argtypes in INT64_GETTERS.items():
+        getattr(lib, name).restype = C.c_int64
+        getattr(lib, name).argtypes = argtypes
     _lib = lib
     return lib
 

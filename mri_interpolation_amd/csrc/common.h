@@ -38,7 +38,8 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Tuning knobs (process-wide, speed only -- never change results beyond fp32 summation order).
 struct Options {
   int xcd_affinity = 1;       // map hash-grid levels to XCDs (blockIdx % 8) so a level's table stays in one L2
-  int bwd_lds_max_parts = 64; // levels needing more LDS partitions than this fall back to global atomics
+  int bwd_lds_max_parts = 256;    // levels cut into more LDS slices than this use global atomics
+  int bwd_blocks_per_level = 64;  // target workgroups per level of the LDS backward (hit balance)
 };
 Options& options();
 

@@ -1,0 +1,481 @@
+// Hash-grid backward for gfx950: table-gradient scatter by BINNING + LDS fixed-point accumulation.
+//
+// Replaces aten::embedding_dense_backward x L plus the mul/sum backward (autograd of reference
+// encoding.py:127-128; 73 % of the reference's CPU step).
+//
+// Why not atomics.  B * L * 2^D (33.5 M at BASELINE config 2/4) gradient rows go to hashed,
+// i.e. random, slots.  Measured on MI355X:
+//   * scattered global_atomic_add_f32: 20 G atomics/s chip-wide (they execute at the memory
+//     side, 64 B per request)                       -> 3.6 ms per step;
+//   * ds_add_f32 (LDS): 0.8 lane-atomics/ns/CU regardless of addresses; ds_add_u64: 13; ds_add_u32: 22
+//     (tools/lds_atomic_bench.hip)                   -> float LDS atomics are no way out either;
+//   * every workgroup scanning the whole batch for the corners of "its" table slice redoes the
+//     hashing 64x                                    -> 1.3 ms.
+// So the contributions are first ROUTED to the workgroup that owns their table slice, then
+// summed there with 64-bit integer LDS atomics:
+//   1. absmax     per-level max|d_out|  -> per-level power-of-two scale 2^e (on device)
+//   2. count      histogram of contributions per bin (bin = level x slice of kAccWords/F slots)
+//   3. prefix     exclusive scan of the bin counts -> bin offsets
+//   4. scatter    recompute the corners, stage (slot, w*g[0..F)) records in LDS grouped by
+//                 bin, copy them out in bin-contiguous runs (coalesced)
+//   5. accumulate one workgroup per bin (big bins: per entry range) adds its records into LDS as
+//                 fixed point (v * 2^e as int64, ds_add_u64), converts once and adds the slice
+//                 to d_table with coalesced accesses
+//   6. finalize   bins that were cut into several entry ranges meet in an int64 workspace.
+// Integer addition is associative: the table gradient is BITWISE REPRODUCIBLE (independent of
+// scheduling and of the order the records landed in), and more accurate than an f32 running sum
+// (>= 40 fraction bits below max|g|; |sum| <= n * max|g| < 2^61 cannot overflow).
+// Algorithmic traffic: records are 4*(1+F) bytes, written once and read once.
+#include <algorithm>
+
+#include "hashgrid_common.h"
+
+namespace mri {
+namespace {
+
+constexpr int kAccWords = 16384;  // 128 KiB of u64 accumulators per accumulate workgroup
+constexpr int kAccThreads = 1024;
+constexpr int kStageWords = 24576;  // 96 KiB LDS staging buffer of the scatter kernel
+constexpr int kBinThreads = 1024;
+constexpr int kMaxParts = 256;        // slices per level handled by the binned path
+constexpr int kHeaderWords = 64;      // per-level max|g| bits
+constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
+
+struct BinPlan {
+  int32_t n_entries;                 // levels handled by the binned path
+  int32_t log2_slots;                // slice = 2^log2_slots table slots
+  int32_t coords_per_block;          // of the count / scatter kernels
+  int32_t total_bins;
+  int32_t level_of[MRI_MAX_LEVELS];
+  int32_t parts[MRI_MAX_LEVELS];     // slices (bins) of the level
+  int32_t bin_start[MRI_MAX_LEVELS];  // first bin of the level
+  int32_t splits[MRI_MAX_LEVELS];    // accumulate workgroups per bin
+  int32_t acc_start[MRI_MAX_LEVELS + 1];  // first accumulate workgroup of the level
+  int64_t ws_offset[MRI_MAX_LEVELS];      // int64 words; -1 = single owner, direct flush
+};
+
+struct Workspace {  // carved out of the caller's buffer
+  uint32_t* max_bits;   // [kHeaderWords]       zero between calls
+  uint32_t* cursor;     // [kMaxBins]           zero between calls
+  uint32_t* offsets;    // [kMaxBins + 1]
+  unsigned long long* partial;  // [ws_words]   zero between calls
+  uint32_t* rec_slot;   // [records]
+  float* rec_val;       // [F][records]
+  int64_t records;
+};
+
+__device__ __forceinline__ int level_exponent(uint32_t max_bits, int64_t n) {
+  // e with n * max|g| * 2^e < 2^61: max|g| < 2^(E+1) (E = unbiased exponent), n < 2^log_n
+  const int E = (int)((max_bits >> 23) & 255u) - 127;
+  const int log_n = 64 - __clzll((unsigned long long)n);
+  const int e = 61 - (E + 1) - log_n;
+  return max(-90, min(e, 120));
+}
+
+__device__ __forceinline__ long long to_fixed(float v, float scale_hi) {
+  // v * 2^e as int64 (e = log2(scale_hi) + 32): integer part of v * 2^(e-32) in the high
+  // word, 31 more bits from the remainder.  Every step but the final truncation is exact.
+  const float t = v * scale_hi;
+  const int hi = (int)t;
+  const float rem = t - (float)hi;
+  const int lo = (int)(rem * 2147483648.0f);
+  return ((long long)hi << 32) + ((long long)lo << 1);
+}
+
+// Exclusive prefix sum of `count` <= 64 * kPerLane values in LDS by ONE wave (call from wave 0):
+// out[i] = sum of in[0..i), out[count] = total.
+template <int kPerLane>
+__device__ __forceinline__ void wave_exclusive_scan(const uint32_t* in, uint32_t* out, int count) {
+  const int lane = threadIdx.x & 63;
+  uint32_t v[kPerLane], sum = 0;
+#pragma unroll
+  for (int j = 0; j < kPerLane; ++j) {
+    const int idx = lane * kPerLane + j;
+    v[j] = idx < count ? in[idx] : 0u;
+    sum += v[j];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  uint32_t run = incl - sum;
+#pragma unroll
+  for (int j = 0; j < kPerLane; ++j) {
+    const int idx = lane * kPerLane + j;
+    if (idx < count) out[idx] = run;
+    run += v[j];
+  }
+  if (lane == 63) out[count] = incl;
+}
+
+// ------------------------------------------------------------------------------ 1. absmax
+template <int F>
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ d_out, int64_t n,
+                                                     int64_t sl, int64_t sr, int64_t sf,
+                                                     uint32_t* __restrict__ max_bits) {
+  const int level = blockIdx.y;
+  const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(gl[i * sr + f * sf]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_bits + level, __float_as_uint(m));
+}
+
+// ------------------------------------------------------------------------ 2. count / 4. scatter
+// One workgroup = (chunk of coords_per_block coordinates, level).  Both kernels walk the same
+// corners in the same way; `SCATTER` selects what is done with them.
+template <int D, int F, bool SCATTER>
+__global__ __launch_bounds__(kBinThreads) void bin_kernel(
+    const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
+    const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
+    uint32_t* __restrict__ cursor, uint32_t* __restrict__ rec_slot, float* __restrict__ rec_val,
+    int64_t records) {
+  __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
+  __shared__ uint32_t local_off[kMaxParts + 1];
+  __shared__ uint32_t global_base[kMaxParts];
+  __shared__ uint32_t stage[SCATTER ? kStageWords : 1];
+
+  const int e = blockIdx.y;
+  const int level = plan.level_of[e];
+  const int parts = plan.parts[e];
+  const uint32_t size = tab.size[level], magic = tab.magic[level];
+  const bool pow2 = tab.pow2[level] != 0;
+  const uint32_t slot_mask = (1u << plan.log2_slots) - 1u;
+  const float* __restrict__ res = tab.res[level];
+  const int64_t i_begin = (int64_t)blockIdx.x * plan.coords_per_block;
+  const int64_t i_end = min(n, i_begin + plan.coords_per_block);
+
+  for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
+  __syncthreads();
+
+  // pass A: histogram of the corners' bins
+  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
+    uint32_t h0[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) h0[d] = (uint32_t)(int)(x[i * D + d] * res[d]) * kPrimes[d];
+#pragma unroll
+    for (int nb = 0; nb < (1 << D); ++nb) {
+      uint32_t h = 0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
+      atomicAdd(&hist[slot_of(h, size, magic, pow2) >> plan.log2_slots], 1u);
+    }
+  }
+  __syncthreads();
+
+  if (!SCATTER) {
+    for (int p = threadIdx.x; p < parts; p += kBinThreads)
+      if (hist[p]) atomicAdd(cursor + plan.bin_start[e] + p, hist[p]);
+    return;
+  }
+
+  // reserve a run in every bin, and lay the runs out back to back in the staging buffer
+  if (threadIdx.x < 64) wave_exclusive_scan<kMaxParts / 64>(hist, local_off, parts);
+  __syncthreads();
+  for (int p = threadIdx.x; p < parts; p += kBinThreads) {
+    global_base[p] = hist[p] ? atomicAdd(cursor + plan.bin_start[e] + p, hist[p]) : 0u;
+    hist[p] = 0u;  // becomes the fill counter of pass B
+  }
+  __syncthreads();
+
+  // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
+  const uint32_t total = local_off[parts];
+  const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
+    const Cell<D> c = locate<D>(x, i, res);
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = gl[i * sr + f * sf];
+#pragma unroll
+    for (int nb = 0; nb < (1 << D); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, nb, h, w);
+      const uint32_t slot = slot_of(h, size, magic, pow2);
+      const uint32_t p = slot >> plan.log2_slots;
+      const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+      stage[pos] = slot & slot_mask;
+#pragma unroll
+      for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
+    }
+  }
+  __syncthreads();
+
+  // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = wave; p < parts; p += kBinThreads / 64) {
+    const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+    const uint64_t dst = (uint64_t)global_base[p];
+    for (uint32_t k = lane; k < cnt; k += 64) {
+      rec_slot[dst + k] = stage[lo + k];
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+        rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ 3. prefix
+// Bin counts (in `cursor`) -> exclusive offsets; `cursor` then holds each bin's write cursor.
+__global__ __launch_bounds__(1024) void bin_prefix_kernel(uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ offsets,
+                                                          int total_bins) {
+  __shared__ uint32_t chunk_sum[1024];
+  __shared__ uint32_t chunk_off[1025];
+  const int per = (total_bins + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(total_bins, lo + per);
+  uint32_t s = 0;
+  for (int b = lo; b < hi; ++b) s += cursor[b];
+  chunk_sum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) wave_exclusive_scan<16>(chunk_sum, chunk_off, 1024);
+  __syncthreads();
+  uint32_t run = chunk_off[threadIdx.x];
+  for (int b = lo; b < hi; ++b) {
+    const uint32_t v = cursor[b];
+    offsets[b] = run;
+    cursor[b] = run;
+    run += v;
+  }
+  if (threadIdx.x == 0) offsets[total_bins] = chunk_off[1024];
+}
+
+// ------------------------------------------------------------------------------ 5. accumulate
+template <int F>
+__global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
+    const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ rec_slot, const float* __restrict__ rec_val, int64_t records,
+    const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
+    unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long acc[kAccWords];
+  const int b = blockIdx.x;
+  int e = 0;
+  while (e + 1 < plan.n_entries && b >= plan.acc_start[e + 1]) ++e;
+  const int level = plan.level_of[e];
+  const int splits = plan.splits[e];
+  const int part = (b - plan.acc_start[e]) / splits, split = (b - plan.acc_start[e]) % splits;
+  const uint32_t slots = 1u << plan.log2_slots;
+  const uint32_t base = (uint32_t)part * slots;
+  const uint32_t count = min(slots, tab.size[level] - base);
+  const int bin = plan.bin_start[e] + part;
+  const uint32_t r_lo = offsets[bin], r_cnt = offsets[bin + 1] - r_lo;
+  const uint32_t per = (r_cnt + splits - 1) / splits;
+  const uint32_t k_lo = min(r_cnt, (uint32_t)split * per), k_hi = min(r_cnt, k_lo + per);
+  if (k_lo >= k_hi) return;  // nothing routed here (uniform for the workgroup)
+
+  for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
+  __syncthreads();
+  const int ex = level_exponent(max_bits[level], n);
+  const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
+  for (uint32_t k = k_lo + threadIdx.x; k < k_hi; k += kAccThreads) {
+    const uint32_t rel = rec_slot[(uint64_t)r_lo + k];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const float v = rec_val[(uint64_t)f * records + r_lo + k];
+      atomicAdd(&acc[rel * F + f], (unsigned long long)to_fixed(v, scale_hi));
+    }
+  }
+  __syncthreads();
+  const int64_t ws_off = plan.ws_offset[e];
+  if (ws_off < 0) {  // sole owner of the slice: convert once, add to the f32 gradient
+    const double inv_scale = __builtin_ldexp(1.0, -ex);
+    float* __restrict__ dst = d_table + (tab.offset[level] + base) * F;
+    for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) {
+      const long long v = (long long)acc[s];
+      if (v) dst[s] += (float)((double)v * inv_scale);
+    }
+  } else {  // one entry range of a big bin: meet the other ranges in the integer workspace
+    unsigned long long* __restrict__ dst = partial + ws_off + (uint64_t)base * F;
+    for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
+      if (acc[s]) atomicAdd(dst + s, acc[s]);
+  }
+}
+
+// ------------------------------------------------------------------------------ 6. finalize
+__global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, const BinPlan plan,
+                                                           int F, int64_t n,
+                                                           float* __restrict__ d_table,
+                                                           const uint32_t* __restrict__ max_bits,
+                                                           unsigned long long* __restrict__ partial) {
+  const int e = blockIdx.y;
+  if (plan.ws_offset[e] < 0) return;
+  const int level = plan.level_of[e];
+  const double inv_scale = __builtin_ldexp(1.0, -level_exponent(max_bits[level], n));
+  const uint64_t words = (uint64_t)tab.size[level] * F;
+  unsigned long long* __restrict__ src = partial + plan.ws_offset[e];
+  float* __restrict__ dst = d_table + tab.offset[level] * F;
+  for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < words;
+       s += (uint64_t)gridDim.x * 256) {
+    const long long v = (long long)src[s];
+    if (v) {
+      dst[s] += (float)((double)v * inv_scale);
+      src[s] = 0ull;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bin_reset_kernel(uint32_t* __restrict__ max_bits,
+                                                        uint32_t* __restrict__ cursor,
+                                                        int total_bins) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < kHeaderWords) max_bits[t] = 0u;
+  if (t < total_bins) cursor[t] = 0u;
+}
+
+// ------------------------------------------------------------------------------ host side
+// Which levels take the binned path and how the kernels are cut; returns false if none does.
+bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uint32_t& atomic_mask,
+               int64_t& ws_words, int64_t& records, int& acc_blocks) {
+  const int F = g->n_features, D = g->dim;
+  plan = BinPlan{};
+  atomic_mask = 0;
+  ws_words = records = 0;
+  acc_blocks = 0;
+  const int slots = kAccWords / F;
+  plan.log2_slots = 31 - __builtin_clz((unsigned)slots);
+  const int per_coord = (1 + F) << D;  // staging words per coordinate
+  plan.coords_per_block = std::min(1024, kStageWords / per_coord / 64 * 64);
+  const bool supported = D <= 4 && F <= 4 && plan.coords_per_block >= 64;
+  const int target = options().bwd_blocks_per_level;
+  for (int l = 0; l < g->n_levels; ++l) {
+    const int parts = (int)ceil_div(g->table_size[l], slots);
+    const bool binned = supported && parts <= kMaxParts &&
+                        (method == 2 || (method == 0 && parts <= options().bwd_lds_max_parts));
+    if (!binned) {
+      atomic_mask |= 1u << l;
+      continue;
+    }
+    const int e = plan.n_entries++;
+    // a level has n * 2^D records; aim at `target` accumulate workgroups per level
+    int splits = std::max(1, target / parts);
+    splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, (n << D) / parts / 4096));
+    plan.level_of[e] = l;
+    plan.parts[e] = parts;
+    plan.bin_start[e] = plan.total_bins;
+    plan.total_bins += parts;
+    plan.splits[e] = splits;
+    plan.acc_start[e] = acc_blocks;
+    acc_blocks += parts * splits;
+    plan.acc_start[e + 1] = acc_blocks;
+    plan.ws_offset[e] = -1;
+    if (splits > 1) {
+      plan.ws_offset[e] = ws_words;
+      ws_words += (int64_t)g->table_size[l] * F;
+    }
+    records += n << D;
+  }
+  return plan.n_entries > 0;
+}
+
+int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
+  return (int64_t)kHeaderWords * 4 + (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 4 +
+         ws_words * 8 + records * 4 * (1 + F) + 64;
+}
+
+Workspace carve(void* base, int64_t ws_words, int64_t records, int F) {
+  Workspace w{};
+  char* p = static_cast<char*>(base);
+  w.max_bits = reinterpret_cast<uint32_t*>(p);
+  p += kHeaderWords * 4;
+  w.cursor = reinterpret_cast<uint32_t*>(p);
+  p += (int64_t)kMaxBins * 4;
+  w.offsets = reinterpret_cast<uint32_t*>(p);
+  p += (int64_t)(kMaxBins + 1) * 4 + 4;  // keeps the next field 8-byte aligned
+  w.partial = reinterpret_cast<unsigned long long*>(p);
+  p += ws_words * 8;
+  w.rec_slot = reinterpret_cast<uint32_t*>(p);
+  p += records * 4;
+  w.rec_val = reinterpret_cast<float*>(p);
+  w.records = records;
+  return w;
+}
+
+template <int D, int F>
+struct BinnedLaunch {
+  static int run(const LevelTab& tab, const BinPlan& plan, const Workspace& w, int n_levels,
+                 int acc_blocks, bool any_split, const float* x, const float* d_out, int64_t n,
+                 int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
+    if constexpr (D <= 4 && F <= 4) {
+      const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
+      hipLaunchKernelGGL((absmax_kernel<F>), dim3(64, n_levels), dim3(256), 0, st, d_out, n, sl,
+                         sr, sf, w.max_bits);
+      hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
+                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records);
+      hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
+                         plan.total_bins);
+      hipLaunchKernelGGL((bin_kernel<D, F, true>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
+                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records);
+      hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
+                         dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.rec_slot, w.rec_val,
+                         w.records, w.max_bits, d_table, w.partial);
+      if (any_split)
+        hipLaunchKernelGGL(bin_finalize_kernel, dim3(64, plan.n_entries), dim3(256), 0, st, tab,
+                           plan, F, n, d_table, w.max_bits, w.partial);
+      hipLaunchKernelGGL(bin_reset_kernel, dim3((unsigned)ceil_div(kMaxBins, 256)), dim3(256), 0,
+                         st, w.max_bits, w.cursor, plan.total_bins);
+      return check_launch("hashgrid backward (binned)");
+    } else {
+      return fail(MRI_ERR_UNSUPPORTED, "binned backward supports dim <= 4, n_features <= 4");
+    }
+  }
+};
+
+}  // namespace
+}  // namespace mri
+
+using namespace mri;
+
+extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n) {
+  if (validate(grid)) return -1;
+  BinPlan plan;
+  uint32_t mask;
+  int64_t words, records;
+  int acc_blocks;
+  make_plan(grid, std::max<int64_t>(n, 1), 2, plan, mask, words, records, acc_blocks);
+  return workspace_bytes(words, records, grid->n_features);
+}
+
+extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
+                                     const float* d_out, int64_t n, int64_t dout_level_stride,
+                                     int64_t dout_row_stride, int64_t dout_feat_stride,
+                                     float* d_table, int32_t method, void* workspace,
+                                     int64_t workspace_bytes_given, void* stream) {
+  if (int rc = validate(grid)) return rc;
+  MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
+  MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && d_out && d_table, "NULL device pointer");
+  const int F = grid->n_features;
+  BinPlan plan;
+  uint32_t atomic_mask;
+  int64_t ws_words, records;
+  int acc_blocks;
+  if (make_plan(grid, n, method, plan, atomic_mask, ws_words, records, acc_blocks)) {
+    MRI_REQUIRE(records < (1ll << 32), "too many gradient records (%lld)", (long long)records);
+    const int64_t need = workspace_bytes(ws_words, records, F);
+    MRI_REQUIRE(workspace != nullptr && workspace_bytes_given >= need,
+                "hashgrid backward needs a workspace of %lld bytes "
+                "(mri_hashgrid_backward_workspace_bytes), got %lld",
+                (long long)need, (long long)workspace_bytes_given);
+    MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                "workspace must be 8-byte aligned");
+    const Workspace w = carve(workspace, ws_words, records, F);
+    const LevelTab tab = make_tab(grid);
+    int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, w, grid->n_levels, acc_blocks,
+                                    ws_words > 0, x, d_out, n, dout_level_stride, dout_row_stride,
+                                    dout_feat_stride, d_table, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (atomic_mask)
+    return launch_backward_atomic(grid, atomic_mask, x, d_out, n, dout_level_stride,
+                                  dout_row_stride, dout_feat_stride, d_table,
+                                  (hipStream_t)stream);
+  return MRI_OK;
+}

@@ -1,0 +1,117 @@
+// Pieces shared by the hash-grid forward (hashgrid.hip) and backward (hashgrid_bwd.hip) kernels.
+#pragma once
+#include "common.h"
+
+namespace mri {
+
+constexpr uint32_t kPrimes[MRI_MAX_DIM] = {1u,          2654435761u, 805459861u, 3674653429u,
+                                           2097192037u, 1434869437u, 2165219737u};
+
+struct LevelTab {
+  float res[MRI_MAX_LEVELS][MRI_MAX_DIM + 1];
+  uint32_t size[MRI_MAX_LEVELS];
+  uint32_t magic[MRI_MAX_LEVELS];  // floor(2^32 / size) when size is not a power of two
+  uint32_t pow2[MRI_MAX_LEVELS];   // 1 -> slot = h & (size-1)
+  uint64_t offset[MRI_MAX_LEVELS];
+};
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t size, uint32_t magic, bool pow2) {
+  if (pow2) return h & (size - 1u);
+  // q in {floor(h/size) - 1, floor(h/size)} since magic = floor(2^32/size)
+  uint32_t q = __umulhi(h, magic);
+  uint32_t r = h - q * size;
+  return r >= size ? r - size : r;
+}
+
+// corner loops are fully unrolled up to 4-D (16 corners), by 2 beyond
+template <int D>
+constexpr int kCornerUnroll = D <= 4 ? (1 << D) : 2;
+
+template <int D>
+struct Cell {
+  uint32_t h0[D];  // hash term of the floor vertex on axis d; the ceil vertex adds the prime
+  float f[D];      // fractional position
+};
+
+template <int D>
+__device__ __forceinline__ Cell<D> locate(const float* __restrict__ x, int64_t i, const float* res) {
+  Cell<D> c;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float pos = x[i * D + d] * res[d];
+    int cell = (int)pos;  // truncation toward zero, as torch .long()
+    c.f[d] = pos - (float)cell;
+    c.h0[d] = (uint32_t)cell * kPrimes[d];
+  }
+  return c;
+}
+
+template <int D>
+__device__ __forceinline__ void corner(const Cell<D>& c, int n, uint32_t& h, float& w) {
+  h = 0;
+  w = 1.0f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const bool hi = (n >> d) & 1;
+    h ^= hi ? c.h0[d] + kPrimes[d] : c.h0[d];
+    const float wd = hi ? c.f[d] : 1.0f - c.f[d];
+    w = (d == 0) ? wd : w * wd;
+  }
+}
+
+inline int validate(const mri_grid_desc* g) {
+  MRI_REQUIRE(g != nullptr, "grid descriptor is NULL");
+  MRI_REQUIRE(g->dim >= 1 && g->dim <= MRI_MAX_DIM, "dim %d not in 1..%d", g->dim, MRI_MAX_DIM);
+  MRI_REQUIRE(g->n_levels >= 1 && g->n_levels <= MRI_MAX_LEVELS, "n_levels %d not in 1..%d",
+              g->n_levels, MRI_MAX_LEVELS);
+  MRI_REQUIRE(g->n_features == 1 || g->n_features == 2 || g->n_features == 4 ||
+                  g->n_features == 8,
+              "n_features %d not in {1,2,4,8}", g->n_features);
+  for (int l = 0; l < g->n_levels; ++l)
+    MRI_REQUIRE(g->table_size[l] >= 1 && g->table_size[l] <= (1u << 30),
+                "table_size[%d] = %u not in 1..2^30", l, g->table_size[l]);
+  return MRI_OK;
+}
+
+inline LevelTab make_tab(const mri_grid_desc* g) {
+  LevelTab t{};
+  for (int l = 0; l < g->n_levels; ++l) {
+    for (int d = 0; d < g->dim; ++d) t.res[l][d] = g->resolution[l][d];
+    const uint32_t s = g->table_size[l];
+    t.size[l] = s;
+    t.pow2[l] = (s & (s - 1)) == 0;
+    t.magic[l] = t.pow2[l] ? 0u : (uint32_t)((1ull << 32) / s);
+    t.offset[l] = g->table_offset[l];
+  }
+  return t;
+}
+
+template <template <int, int> class Launch, typename... Args>
+int dispatch(int dim, int feats, Args&&... args) {
+#define MRI_CASE_F(DD)                                                   \
+  switch (feats) {                                                       \
+    case 1: return Launch<DD, 1>::run(args...);                          \
+    case 2: return Launch<DD, 2>::run(args...);                          \
+    case 4: return Launch<DD, 4>::run(args...);                          \
+    case 8: return Launch<DD, 8>::run(args...);                          \
+  }                                                                      \
+  break;
+  switch (dim) {
+    case 1: MRI_CASE_F(1)
+    case 2: MRI_CASE_F(2)
+    case 3: MRI_CASE_F(3)
+    case 4: MRI_CASE_F(4)
+    case 5: MRI_CASE_F(5)
+    case 6: MRI_CASE_F(6)
+    case 7: MRI_CASE_F(7)
+  }
+#undef MRI_CASE_F
+  return fail(MRI_ERR_UNSUPPORTED, "no kernel for dim %d, n_features %d", dim, feats);
+}
+
+// global-atomic backward for the levels selected by `level_mask` (hashgrid.hip)
+int launch_backward_atomic(const mri_grid_desc* grid, uint32_t level_mask, const float* x,
+                           const float* d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
+                           float* d_table, hipStream_t st);
+
+}  // namespace mri

@@ -89,6 +89,20 @@ def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
     return out
 
 
+_bwd_workspace = {}  # device index -> zero-initialised scratch (the library re-zeroes it)
+
+
+def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
+    need = _lib.load().mri_hashgrid_backward_workspace_bytes(C.byref(desc), n)
+    if need < 0:
+        _lib.check(-1, "mri_hashgrid_backward_workspace_bytes")
+    ws = _bwd_workspace.get(device.index)
+    if ws is None or ws.numel() * 8 < need:
+        ws = torch.zeros((need + 7) // 8, dtype=torch.int64, device=device)
+        _bwd_workspace[device.index] = ws
+    return ws
+
+
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                       d_table: torch.Tensor, feature_major: bool = False, method: int = 0):
     """d_table += scatter of d_out (accumulates)."""
@@ -98,8 +112,10 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
     if not d_out.is_contiguous():
         d_out = d_out.contiguous()
     sl, sr, sf = _enc_strides(desc, n, feature_major)
+    ws = backward_workspace(desc, n, x.device) if method != 1 else None
     _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
-              _ptr(d_table), method, _stream())
+              _ptr(d_table), method, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
+              _stream())
     return d_table
 
 
