@@ -1,0 +1,154 @@
+"""Host-side logic of the package (no GPU): level tables, NIfTI I/O, config, sharding,
+model surfaces and state-dict layout, launcher plumbing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import hashgrid as ohash
+
+from mri_interpolation_amd import config as cfg
+from mri_interpolation_amd import encoding, models, nifti, parallel, trainer
+
+
+@pytest.mark.parametrize("args", [
+    (3, 16, 19, 16, 512), (3, 16, 19, 16, 16 * 1.4 ** 15), (4, 16, 19, 16, 16 * 1.4 ** 15),
+    (2, 16, 15, 16, 512), (3, 4, 23, (64, 64, 5), (352, 352, 15)),
+    (3, 8, 23, (64, 64, 5), (512, 512, 15))])
+def test_level_table_matches_oracle(args):
+    assert encoding.level_table(*args) == ohash.level_geometry(*args)
+
+
+def test_encoder_surface_and_state_dict():
+    enc = encoding.MultiResHashGrid(3, 16, 2, 19, 16, 512)
+    assert (enc.input_dim, enc.output_dim) == (3, 32)
+    assert 2 * enc.table.shape[0] == 10435874
+    assert enc.levels[3].hashmap_size == 32768 and enc.levels[3].resolution == 32
+    assert enc.levels[2].embedding.weight.shape == (15625, 2)
+    assert float(enc.table.abs().max()) <= 1e-4
+    sd = enc.state_dict()
+    assert list(sd) == [f"levels.{i}.embedding.weight" for i in range(16)]
+    enc2 = encoding.MultiResHashGrid(3, 16, 2, 19, 16, 512)
+    enc2.load_state_dict(sd)
+    assert torch.equal(enc2.table, enc.table)
+    v2 = encoding.MultiResHashGridV2(3, 4, 1, 23, (64, 64, 5), (352, 352, 15))
+    assert v2.sizes == [262144, 274625, 300763, 328509]
+    assert torch.equal(v2.levels[1].resolution, torch.tensor([65.0, 65.0, 6.0]))
+    with pytest.raises(ValueError):
+        encoding.MultiResHashGridV2(4, 4, 1, 23, (64, 64, 5), (352, 352, 15))
+
+
+def test_model_surfaces_match_reference_keys():
+    fx = load_golden("hashmlp_intended")
+    net = models.HashMLP(dim_in=3, n_levels=4, n_features_per_level=1, log2_hashmap_size=23,
+                         base_resolution=(64, 64, 5), finest_resolution=(352, 352, 15),
+                         dim_hidden=64, dim_out=1, n_layers=2)
+    ref = [k for k in fx.meta["state_dict_keys"] if not k.startswith("layers.")]
+    assert sorted(net.state_dict()) == sorted(ref)
+    # a reference checkpoint (with BaseMLP's dead `layers.*` entries) loads
+    sd = dict(net.state_dict())
+    sd["layers.0.weight"], sd["layers.0.bias"] = torch.zeros(128, 2), torch.zeros(128)
+    net.load_state_dict(sd)
+    siren = models.SirenNet(dim_in=3, dim_hidden=256, dim_out=1, n_layers=5)
+    assert sum(p.numel() for p in siren.parameters()) == 264449
+    assert list(siren.state_dict())[:2] == ["layers.0.weight", "layers.0.bias"]
+    assert "last_layer.weight" in siren.state_dict()
+    w = siren.layers[0].weight
+    assert float(w.abs().max()) <= 1 / 3 and float(siren.layers[1].weight.abs().max()) <= \
+        np.sqrt(6 / 256) / 30
+    mlp = models.BaseMLP(dim_in=32, dim_out=1, dim_hidden=64, n_layers=3)
+    assert sorted(mlp.state_dict()) == sorted(f"layers.{2 * i}.{p}" for i in range(3)
+                                              for p in ("weight", "bias"))
+    assert trainer.fusable_layers(siren) is not None and trainer.fusable_layers(net) is None
+    tiny = models.HashMLP(3, 16, 2, 19, 16, 512, dim_hidden=64, n_layers=3,
+                          activation=torch.nn.ReLU, batch_norm=False, final_activation=False)
+    enc, layers = trainer.fusable_layers(tiny)
+    assert enc is tiny.encoder and [l.weight.shape for l in layers] == [(64, 32), (64, 64), (1, 64)]
+    assert sum(p.numel() for p in tiny.parameters()) == 10442211  # SURVEY 8(d) cfg 2
+
+
+def test_cpu_forward_is_refused():
+    net = models.SirenNet(dim_in=2, dim_hidden=16, dim_out=1, n_layers=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.rand(4, 2))
+
+
+def test_nifti_round_trip_and_sample_slice(tmp_path):
+    vol = (np.arange(6 * 5 * 4 * 3, dtype=np.float32).reshape(6, 5, 4, 3) - 17.0) * 0.5
+    for name in ("a.nii.gz", "b.nii"):
+        path = str(tmp_path / name)
+        nifti.save(vol, path)
+        assert nifti.read_header(path)["shape"] == (6, 5, 4, 3)
+        np.testing.assert_array_equal(nifti.load(path), vol)
+    # int16 + scl_slope, Fortran order: the sample's storage format
+    fx = load_golden("sample_slice_z3_t7")
+    raw = fx["raw_int16"]
+    path = str(tmp_path / "s.nii.gz")
+    nifti.save(raw, path)
+    np.testing.assert_array_equal(nifti.load(path), raw.astype(np.float32))
+    sample = "/root/reference/sample_ankle_dyn_mri.nii.gz"
+    if os.path.exists(sample):  # only in the build container
+        full = nifti.load(sample)
+        assert full.shape == (352, 352, 6, 15)
+        want = (raw.astype(np.float64) * fx.meta["scl_slope"]).astype(np.float32)
+        np.testing.assert_array_equal(full[:, :, 3, 7], want)
+
+
+def test_config_defaults_and_json_mapping(tmp_path):
+    c = cfg.HashConfig().resolve((352, 352, 15))
+    assert (c.dim_in, c.n_levels, c.n_features_per_level, c.log2_hashmap_size) == (3, 4, 1, 23)
+    assert c.base_resolution == (64, 64, 5) and c.lr == 5e-3 and c.batch_size == 10000
+    b = cfg.BaseConfig()
+    assert (b.dim_hidden, b.n_layers, b.batch_size, b.lr, b.w0) == (128, 6, 4096, 1e-4, 30.0)
+    enc = cfg.encoder_from_json(cfg.load_json(os.path.join(ROOT, "config", "hash_config.json")), 3)
+    res, sizes = encoding.level_table(3, enc["n_levels"], enc["log2_hashmap_size"],
+                                      enc["base_resolution"], enc["finest_resolution"])
+    assert [r[0] for r in res][-3:] == [1269, 1777, 2489] and 2 * sum(sizes) == 12236382
+    cfg.apply_overrides(c, dict(batch_size=77, epochs=None))
+    assert c.batch_size == 77 and c.epochs == 1
+    c.export_to_txt(str(tmp_path))
+    assert "batch_size : 77" in open(tmp_path / "config.txt").read()
+    assert cfg.parse_slice(":,:,3,7") == (slice(None), slice(None), 3, 7)
+
+
+def test_sharding_ranges():
+    spans = [parallel.voxel_range((256, 256, 256), r, 8) for r in range(8)]
+    assert spans[0] == (0, 32 * 65536) and spans[-1][1] == 256 ** 3
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # the sample has 6 z-slices... and 352 x-slices: slowest axis (x) is sharded
+    spans = [parallel.voxel_range((352, 352, 6, 15), r, 8) for r in range(8)]
+    assert spans[3] == (3 * 44 * 352 * 90, 4 * 44 * 352 * 90)
+    # fewer slices than ranks: contiguous flat split
+    spans = [parallel.voxel_range((6, 100), r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 600 and all(b - a == 75 for a, b in spans)
+    assert [parallel.slab_range(6, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 6)]
+    with pytest.raises(ValueError):
+        parallel.slab_range(6, 0, 8)
+
+
+def test_launcher_cli_and_model_factory():
+    import launcher
+    args = launcher.parse_args(["--batch_size", "4096", "--epochs", "2", "--model_class",
+                                "SirenNet", "--slice", ":,:,3,7"])
+    assert (args.batch_size, args.epochs, args.model_class, args.slice_spec) == \
+        (4096, 2, "SirenNet", ":,:,3,7")
+    c = cfg.apply_overrides(cfg.BaseConfig(), dict(model_class="SirenNet")).resolve((352, 352))
+    net = launcher.build_model(c, models)  # SirenNet takes no hash kwargs
+    assert isinstance(net, models.SirenNet) and net.layers[0].weight.shape == (128, 2)
+    h = cfg.HashConfig().resolve((352, 352, 15))
+    assert isinstance(launcher.build_model(h, models), models.HashMLP)
+
+
+def test_interp_baseline_is_linear_in_time():
+    import interp
+    t = np.arange(15, dtype=np.float64)
+    data = np.broadcast_to(3.0 * t + 1.0, (4, 5, 15)).copy()
+    out = interp.interpolate_even_frames(data)
+    np.testing.assert_allclose(out, data, rtol=0, atol=1e-12)  # exact on a linear ramp
+    data2 = np.random.default_rng(0).random((3, 3, 8))
+    out2 = interp.interpolate_even_frames(data2)
+    np.testing.assert_array_equal(out2[..., ::2], data2[..., ::2])
+    np.testing.assert_allclose(out2[..., 1], 0.5 * (data2[..., 0] + data2[..., 2]))
+    np.testing.assert_array_equal(out2[..., 7], data2[..., 6])  # beyond the last even frame
