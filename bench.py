@@ -54,7 +54,7 @@ def phase_model(w, step, n_params):
     dims = [l.weight.shape[1] for l in step.layers] + [step.layers[-1].weight.shape[0]]
     mac = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     out = {"mlp_fwd": ("mfma", 2.0 * mac * b), "mlp_bwd": ("mfma", 4.0 * mac * b),
-           "adam": ("hbm", 28.0 * n_params)}
+           "mlp_fused": ("mfma", 6.0 * mac * b), "adam": ("hbm", 28.0 * n_params)}
     if step.encoder is not None:
         e = step.encoder
         corners = (1 << e.dim) * e.n_levels * e.n_features_per_level * 4

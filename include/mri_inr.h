@@ -140,6 +140,35 @@ int mri_linear_backward_weight(const float* dy, int64_t lddy, const float* x,
 int mri_apply_deriv(float* dy, int64_t lddy, int32_t deriv_mode, const float* deriv,
                     int64_t ldd, int64_t m, int32_t n, void* stream);
 
+/* ---- fused tiny MLP ------------------------------------------------------------------------
+ * The decoder of BASELINE configs 2/4/5: k_in -> hidden -> hidden -> 1, ReLU on the hidden
+ * layers, linear output (reference config/hash_config.json "network"; module form
+ * models.py:46-56 / 730-744 with ReLU, no BatchNorm).  ONE persistent kernel per call:
+ * weights resident in LDS, activations never leave the CU, all products on f32 MFMA.
+ *   x        (k_in, n) FEATURE-MAJOR input features (the layout mri_hashgrid_forward writes)
+ *   w1 (hidden, k_in), w2 (hidden, hidden), w3 (1, hidden) row-major as nn.Linear stores them
+ * mri_tiny_mlp_supported: 1 if (k_in, hidden, dim_out) has a fused kernel
+ *   (hidden 128 with k_in <= 32, hidden 64 with k_in <= 64, dim_out 1), else 0.
+ * mri_tiny_mlp_forward:  y[n] = MLP(x).
+ * mri_tiny_mlp_train:    forward + F.mse_loss(target, y) + backward in one pass:
+ *   d_w*, d_b* += parameter gradients, loss_out[0] += mean squared error,
+ *   d_x (k_in, n) feature-major = dLoss/dx (optional, may be NULL), y (optional) predictions.
+ *   Gradients are those of mean((y - target)^2) / grad_divisor.  Per-workgroup partial sums go
+ *   through `workspace` (mri_tiny_mlp_workspace_bytes, no initialisation needed) and are added
+ *   in a fixed order: results are bitwise reproducible. */
+int mri_tiny_mlp_supported(int32_t k_in, int32_t hidden, int32_t dim_out);
+int64_t mri_tiny_mlp_workspace_bytes(int32_t k_in, int32_t hidden, int64_t n);
+int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int32_t hidden, const float* w1,
+                         const float* b1, const float* w2, const float* b2, const float* w3,
+                         const float* b3, float* y, void* stream);
+int mri_tiny_mlp_train(const float* x, const float* target, int64_t n, int32_t k_in,
+                       int32_t hidden, const float* w1, const float* b1, const float* w2,
+                       const float* b2, const float* w3, const float* b3, float grad_divisor,
+                       float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3,
+                       float* d_b3, float* d_x /* may be NULL */, float* loss_out,
+                       float* y /* may be NULL */, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+
 /* ---- loss ------------------------------------------------------------------------------
  * F.mse_loss(y, y_pred) (reference models.py:64): loss_out[0] += mean((pred-target)^2)
  * (device scalar, caller zeroes), d_pred = 2 (pred - target) / (count * grad_divisor) if

@@ -47,12 +47,17 @@ SIGNATURES = {
     "mri_linear_backward_weight": [_P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
     "mri_apply_deriv": [_P, _I64, _I32, _P, _I64, _I64, _I32, _P],
     "mri_mse_loss": [_P, _P, _I64, _F, _P, _P, _P],
+    "mri_tiny_mlp_forward": [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mri_tiny_mlp_train": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+                           _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
     "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
-INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64]}
+INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
+                 "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64]}
+INT_GETTERS = {"mri_tiny_mlp_supported": [_I32, _I32, _I32]}  # return a plain value, not a status
 
 _lib = None
 
@@ -84,6 +89,9 @@ def load():
         getattr(lib, name).argtypes = []
     for name, argtypes in INT64_GETTERS.items():
         getattr(lib, name).restype = C.c_int64
+        getattr(lib, name).argtypes = argtypes
+    for name, argtypes in INT_GETTERS.items():
+        getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = argtypes
     _lib = lib
     return lib

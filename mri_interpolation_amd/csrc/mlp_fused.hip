@@ -1,0 +1,474 @@
+// Fully fused tiny-MLP (ReLU) forward + MSE + backward for gfx950: one kernel per training step.
+//
+// Replaces, for the decoder of BASELINE configs 2/4/5 (in -> H -> H -> 1, ReLU hidden, linear
+// output; config/hash_config.json "network"), the op chain F.linear/ReLU x3 + F.mse_loss and its
+// whole autograd (reference models.py:46-66, 730-744): 3 forward GEMMs, the loss, 5 backward
+// GEMMs and the bias / last-layer reductions -- 12 launches and ~1 GB of activation traffic per
+// step in the layer-wise path -- become ONE persistent kernel that never writes an activation
+// to HBM.
+//
+// Layout of a workgroup (256 threads = 4 waves, one 64-coordinate tile at a time):
+//   LDS  W2 (H x H), W1 (H x K_in), w3, b1, b2          loaded once, resident for the launch
+//        x tile (64 x K_in), h1 (64 x H), h2 (64 x H)   h2 becomes dz2 in place, h1 becomes dz1
+//   VGPR dW2 / dW1 accumulators (f32 MFMA C registers) live across ALL tiles of the workgroup;
+//        bias and last-layer gradients accumulate in plain registers.
+//   All seven products of a tile run on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact f32: the
+//   1e-5 parity target rules out bf16, and gfx950 has no xf32), fragments read from LDS images
+//   whose leading dimensions (H+1, K_in+1) make both orientations of every operand
+//   conflict-free, so W2 and the activations are stored once and read as W2 and W2^T.
+//   Input features arrive feature-major (K_in, n) straight from the hash-grid kernel and the
+//   feature gradient leaves feature-major for the hash-grid backward.
+// At the end every workgroup writes its partial parameter gradients and loss to a workspace
+// slab; a second tiny kernel sums the slabs in a fixed order, so the result is bitwise
+// reproducible (no float atomics anywhere on the training path).
+#include <algorithm>
+
+#include "common.h"
+
+namespace mri {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 64;       // coordinates per workgroup iteration
+constexpr int kThreads = 256;   // 4 waves
+
+struct FusedArgs {
+  const float* x;      // (k_in, n) feature-major
+  const float* target; // (n)
+  const float* w1; const float* b1;   // (H, k_in), (H)
+  const float* w2; const float* b2;   // (H, H), (H)
+  const float* w3; const float* b3;   // (1, H), (1)
+  float* y;            // (n) predictions, optional
+  float* dx;           // (k_in, n) feature-major, optional
+  float* partial;      // [gridDim.x][slab] partial gradients + loss
+  int64_t n;
+  int k_in;
+  float grad_scale;    // 2 / (n * grad_divisor)
+  float inv_n;
+};
+
+template <int H, int KP>
+struct Smem {
+  static constexpr int ldw2 = H + 1, ldw1 = KP + 1, lda = H + 1, ldx = KP + 1;
+  float w2[H * ldw2];
+  float w1[H * ldw1];
+  float h1[kTile * lda];
+  float h2[kTile * lda];
+  float xs[kTile * ldx];
+  float w3[H], b1[H], b2[H];
+  float dy[kTile];
+  float ypart[4 * kTile];
+};
+
+// slab layout (floats): dW1 [H*k_in] | db1 [H] | dW2 [H*H] | db2 [H] | dW3 [H] | db3 [1] | loss [1]
+__host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + H + H * H + H + H + 2; }
+
+// acc[ti][tj] += A(i, c) * B(j, c) over `steps` pairs of contraction indices, 32x32 tiles.
+// a / b point at this lane's element of tile (0,0) for contraction index 0; consecutive tiles are
+// a_tile / b_tile floats apart, consecutive contraction PAIRS a_step / b_step floats apart.
+template <int TI, int TJ>
+__device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __restrict__ a,
+                                       int a_tile, int a_step, const float* __restrict__ b,
+                                       int b_tile, int b_step, int steps) {
+#pragma unroll 4
+  for (int s = 0; s < steps; ++s) {
+    float av[TI], bv[TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) av[ti] = a[ti * a_tile + s * a_step];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) bv[tj] = b[tj * b_tile + s * b_step];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+  }
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void zero(f32x16 (&acc)[TI][TJ]) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+}
+
+// row of a 32x32 MFMA accumulator register: (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+template <int H, int KP, bool TRAIN>
+__global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
+  using S = Smem<H, KP>;
+  __shared__ S sm;
+  constexpr int NB = H / 32;        // 32-wide blocks of the hidden width
+  constexpr int KB32 = KP / 32;     // 32-wide blocks of the (padded) input width
+  // forward tiles: (64 x H) = 2 x NB tiles of 32x32 over 4 waves
+  constexpr int FTI = NB == 4 ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int f_ti0 = NB == 4 ? 0 : (wave >> 1);   // first row block of this wave
+  const int f_tj = NB == 4 ? wave : (wave & 1);  // column block of this wave
+  // weight-gradient tiles: dW2 = NB x NB tiles; wave owns row block(s)
+  constexpr int GTJ = NB == 4 ? 4 : 1;
+  const int g_ob = NB == 4 ? wave : (wave >> 1);
+  const int g_ib0 = NB == 4 ? 0 : (wave & 1);
+
+  // ---- resident weights ---------------------------------------------------------------
+  for (int e = tid; e < H * H; e += kThreads) sm.w2[(e / H) * S::ldw2 + (e % H)] = a.w2[e];
+  for (int e = tid; e < H * KP; e += kThreads) {
+    const int o = e / KP, k = e % KP;
+    sm.w1[o * S::ldw1 + k] = k < a.k_in ? a.w1[o * a.k_in + k] : 0.f;
+  }
+  for (int e = tid; e < H; e += kThreads) {
+    sm.w3[e] = a.w3[e];
+    sm.b1[e] = a.b1[e];
+    sm.b2[e] = a.b2[e];
+  }
+  const float b3 = a.b3[0];
+
+  // persistent accumulators
+  f32x16 g_w2[1][GTJ];
+  f32x16 g_w1[1][1];
+  zero(g_w2);
+  zero(g_w1);
+  float g_b1 = 0.f;                 // wave's forward column block: column f_tj*32 + l31 (both halves)
+  float g_b2 = 0.f, g_w3 = 0.f;     // thread (o = tid % H, half = tid / H) partials
+  float g_b3 = 0.f, loss = 0.f;     // threads < 64
+  const bool dw1_owner = NB == 4 ? true : (KB32 == 2 ? true : wave < 2);
+  const int w1_ob = NB == 4 ? wave : (KB32 == 2 ? (wave >> 1) : wave);
+  const int w1_kb = NB == 4 ? 0 : (KB32 == 2 ? (wave & 1) : 0);
+
+  const int64_t tiles = (a.n + kTile - 1) / kTile;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t m0 = t * kTile;
+    __syncthreads();  // B0: previous tile is done with xs / h1 / h2
+    // ---- stage x tile: xs[c][k] from feature-major x[k][m0 + c] -----------------------------
+    for (int e = tid; e < KP * (kTile / 4); e += kThreads) {
+      const int k = e / (kTile / 4), c4 = (e % (kTile / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < a.k_in) {
+        const float* src = a.x + (int64_t)k * a.n + m0 + c4;
+        if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (m0 + c4 + 0 < a.n) v.x = src[0];
+          if (m0 + c4 + 1 < a.n) v.y = src[1];
+          if (m0 + c4 + 2 < a.n) v.z = src[2];
+          if (m0 + c4 + 3 < a.n) v.w = src[3];
+        }
+      }
+      float* dst = sm.xs + c4 * S::ldx + k;
+      dst[0] = v.x, dst[S::ldx] = v.y, dst[2 * S::ldx] = v.z, dst[3 * S::ldx] = v.w;
+    }
+    __syncthreads();  // B1
+
+    // ---- layer 1: h1 = relu(x W1^T + b1) -----------------------------------------------------
+    {
+      f32x16 acc[FTI][1];
+      zero(acc);
+      mfma32<FTI, 1>(acc, sm.xs + (f_ti0 * 32 + l31) * S::ldx + lh, 32 * S::ldx, 2,
+                     sm.w1 + (f_tj * 32 + l31) * S::ldw1 + lh, 0, 2, KP / 2);
+      const int col = f_tj * 32 + l31;
+      const float bias = sm.b1[col];
+#pragma unroll
+      for (int ti = 0; ti < FTI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sm.h1[((f_ti0 + ti) * 32 + acc_row(r, lh)) * S::lda + col] = fmaxf(acc[ti][0][r] + bias, 0.f);
+    }
+    __syncthreads();  // B2
+    // ---- layer 2: h2 = relu(h1 W2^T + b2) ----------------------------------------------------
+    {
+      f32x16 acc[FTI][1];
+      zero(acc);
+      mfma32<FTI, 1>(acc, sm.h1 + (f_ti0 * 32 + l31) * S::lda + lh, 32 * S::lda, 2,
+                     sm.w2 + (f_tj * 32 + l31) * S::ldw2 + lh, 0, 2, H / 2);
+      const int col = f_tj * 32 + l31;
+      const float bias = sm.b2[col];
+#pragma unroll
+      for (int ti = 0; ti < FTI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sm.h2[((f_ti0 + ti) * 32 + acc_row(r, lh)) * S::lda + col] = fmaxf(acc[ti][0][r] + bias, 0.f);
+    }
+    __syncthreads();  // B3
+    // ---- layer 3 (one output): y[c] = h2[c] . w3 + b3, wave w sums its quarter of H ----------
+    {
+      constexpr int Q = H / 4;
+      const float* row = sm.h2 + lane * S::lda + wave * Q;
+      const float* w = sm.w3 + wave * Q;
+      float s = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < Q; ++o) s += row[o] * w[o];
+      sm.ypart[wave * kTile + lane] = s;
+    }
+    __syncthreads();  // B4
+    if (tid < kTile) {
+      const int64_t m = m0 + tid;
+      const float y = sm.ypart[tid] + sm.ypart[kTile + tid] + sm.ypart[2 * kTile + tid] +
+                      sm.ypart[3 * kTile + tid] + b3;
+      float d = 0.f;
+      if (m < a.n) {
+        if (a.y) a.y[m] = y;
+        if (TRAIN) {
+          const float diff = y - a.target[m];
+          loss += diff * diff;
+          d = diff * a.grad_scale;
+          g_b3 += d;
+        }
+      }
+      sm.dy[tid] = d;
+    }
+    if (!TRAIN) continue;
+    __syncthreads();  // B5
+    // ---- dz2 = (dy w3^T) * (h2 > 0) in place; dW3, db2 partials -------------------------------
+    {
+      constexpr int HALVES = kThreads / H;          // 2 (H = 128) or 4 (H = 64)
+      constexpr int ROWS = kTile / HALVES;
+      const int o = tid % H, c0 = (tid / H) * ROWS;
+      const float w3o = sm.w3[o];
+#pragma unroll 8
+      for (int c = c0; c < c0 + ROWS; ++c) {
+        const float h = sm.h2[c * S::lda + o];
+        const float d = sm.dy[c];
+        g_w3 += d * h;
+        const float dz = h > 0.f ? d * w3o : 0.f;
+        g_b2 += dz;
+        sm.h2[c * S::lda + o] = dz;
+      }
+    }
+    __syncthreads();  // B6
+    // ---- dW2 += dz2^T h1 ; dz1 = (dz2 W2) * (h1 > 0) ------------------------------------------
+    mfma32<1, GTJ>(g_w2, sm.h2 + (g_ob * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                   sm.h1 + (g_ib0 * 32 + l31) + lh * S::lda, 32, 2 * S::lda, kTile / 2);
+    f32x16 dz1[FTI][1];
+    zero(dz1);
+    mfma32<FTI, 1>(dz1, sm.h2 + (f_ti0 * 32 + l31) * S::lda + lh, 32 * S::lda, 2,
+                   sm.w2 + (f_tj * 32 + l31) + lh * S::ldw2, 0, 2 * S::ldw2, H / 2);
+    __syncthreads();  // B7: every wave is done reading h1 as an operand
+    {
+      const int col = f_tj * 32 + l31;
+#pragma unroll
+      for (int ti = 0; ti < FTI; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* p = sm.h1 + ((f_ti0 + ti) * 32 + acc_row(r, lh)) * S::lda + col;
+          const float v = *p > 0.f ? dz1[ti][0][r] : 0.f;
+          g_b1 += v;
+          *p = v;
+        }
+    }
+    __syncthreads();  // B8
+    // ---- dW1 += dz1^T x -------------------------------------------------------------------
+    if (dw1_owner)
+      mfma32<1, 1>(g_w1, sm.h1 + (w1_ob * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                   sm.xs + (w1_kb * 32 + l31) + lh * S::ldx, 0, 2 * S::ldx, kTile / 2);
+    // ---- dx^T = W1^T dz1^T (k_in x 64), 16x16 tiles so that all four waves take part ---------
+    if (a.dx) {
+      constexpr int TILES = (KP / 16) * (kTile / 16);
+      const int l15 = lane & 15, lq = lane >> 4;
+      for (int tile = wave; tile < TILES; tile += 4) {
+        const int kb = tile / (kTile / 16), cb = tile % (kTile / 16);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* pa = sm.w1 + lq * S::ldw1 + kb * 16 + l15;          // A(i = k, kk = o)
+        const float* pb = sm.h1 + (cb * 16 + l15) * S::lda + lq;         // B(kk = o, j = c)
+#pragma unroll 8
+        for (int s = 0; s < H / 4; ++s)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s * 4 * S::ldw1], pb[s * 4], acc, 0, 0, 0);
+        const int64_t m = m0 + cb * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kb * 16 + lq * 4 + r;
+          if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = acc[r];
+        }
+      }
+    }
+  }
+  if (!TRAIN) return;
+
+  // ---- write this workgroup's partial gradients (plain stores, summed by reduce kernel) ----
+  float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
+  float* p_w1 = slab;
+  float* p_b1 = p_w1 + H * a.k_in;
+  float* p_w2 = p_b1 + H;
+  float* p_b2 = p_w2 + H * H;
+  float* p_w3 = p_b2 + H;
+  float* p_b3 = p_w3 + H;
+  __syncthreads();
+  // dW2: wave's tiles
+#pragma unroll
+  for (int tj = 0; tj < GTJ; ++tj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      p_w2[(g_ob * 32 + acc_row(r, lh)) * H + (g_ib0 + tj) * 32 + l31] = g_w2[0][tj][r];
+  // dW1
+  if (dw1_owner) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = w1_ob * 32 + acc_row(r, lh), k = w1_kb * 32 + l31;
+      if (k < a.k_in) p_w1[o * a.k_in + k] = g_w1[0][0][r];
+    }
+  }
+  // db1: column f_tj*32 + l31, two lane halves, and (H = 64) two waves per column block
+  float* red = sm.h2;  // scratch
+  red[tid] = g_b1;
+  __syncthreads();
+  if (tid < H) {
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const int tj = NB == 4 ? w : (w & 1);
+      if (tj == tid / 32) s += red[w * 64 + (tid & 31)] + red[w * 64 + 32 + (tid & 31)];
+    }
+    p_b1[tid] = s;
+  }
+  __syncthreads();
+  red[tid] = g_b2;
+  red[kThreads + tid] = g_w3;
+  __syncthreads();
+  if (tid < H) {
+    float s2 = 0.f, s3 = 0.f;
+    for (int h = 0; h < kThreads / H; ++h) {
+      s2 += red[h * H + tid];
+      s3 += red[kThreads + h * H + tid];
+    }
+    p_b2[tid] = s2;
+    p_w3[tid] = s3;
+  }
+  __syncthreads();
+  if (tid < kTile) {
+    red[tid] = g_b3;
+    red[kTile + tid] = loss;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f, l = 0.f;
+    for (int c = 0; c < kTile; ++c) {
+      s += red[c];
+      l += red[kTile + c];
+    }
+    p_b3[0] = s;
+    p_b3[1] = l * a.inv_n;
+  }
+}
+
+// Sum the per-workgroup slabs in a fixed order into the gradient tensors (accumulating).
+struct ReduceArgs {
+  const float* partial;
+  int slabs, slab;
+  int n_seg;
+  int seg_begin[8];   // offsets inside a slab
+  int seg_len[8];
+  float* dst[8];
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceArgs r) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= r.slab) return;
+  float s = 0.f;
+  for (int b = 0; b < r.slabs; ++b) s += r.partial[(int64_t)b * r.slab + e];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    if (g < r.n_seg && e >= r.seg_begin[g] && e < r.seg_begin[g] + r.seg_len[g])
+      r.dst[g][e - r.seg_begin[g]] += s;
+}
+
+template <int H, int KP>
+int launch(const FusedArgs& a, bool train, int blocks, hipStream_t st) {
+  if (train)
+    hipLaunchKernelGGL((tiny_mlp_kernel<H, KP, true>), dim3(blocks), dim3(kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((tiny_mlp_kernel<H, KP, false>), dim3(blocks), dim3(kThreads), 0, st, a);
+  return check_launch("tiny_mlp_kernel");
+}
+
+int pick_blocks(int hidden, int64_t n) {
+  const int per_cu = hidden == 128 ? 1 : 2;  // LDS footprint: 156 KiB vs 52-75 KiB
+  const int64_t tiles = ceil_div(n, kTile);
+  return (int)std::min<int64_t>(tiles, 256 * per_cu);
+}
+
+bool supported(int k_in, int hidden, int dim_out) {
+  if (dim_out != 1 || k_in < 1) return false;
+  if (hidden == 128) return k_in <= 32;
+  if (hidden == 64) return k_in <= 64;
+  return false;
+}
+
+int dispatch(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
+  if (hidden == 128) return launch<128, 32>(a, train, blocks, st);
+  if (a.k_in <= 32) return launch<64, 32>(a, train, blocks, st);
+  return launch<64, 64>(a, train, blocks, st);
+}
+
+}  // namespace
+}  // namespace mri
+
+using namespace mri;
+
+extern "C" int mri_tiny_mlp_supported(int32_t k_in, int32_t hidden, int32_t dim_out) {
+  return supported(k_in, hidden, dim_out) ? 1 : 0;
+}
+
+extern "C" int64_t mri_tiny_mlp_workspace_bytes(int32_t k_in, int32_t hidden, int64_t n) {
+  if (!supported(k_in, hidden, 1)) return -1;
+  return (int64_t)pick_blocks(hidden, std::max<int64_t>(n, 1)) * slab_floats(hidden, k_in) * 4;
+}
+
+extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int32_t hidden,
+                                    const float* w1, const float* b1, const float* w2,
+                                    const float* b2, const float* w3, const float* b3, float* y,
+                                    void* stream) {
+  MRI_REQUIRE(supported(k_in, hidden, 1), "tiny MLP %d -> %d -> %d -> 1 is not supported", k_in,
+              hidden, hidden);
+  MRI_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && y, "NULL device pointer");
+  FusedArgs a{};
+  a.x = x, a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3, a.y = y;
+  a.n = n, a.k_in = k_in;
+  return dispatch(a, hidden, false, pick_blocks(hidden, n), (hipStream_t)stream);
+}
+
+extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n, int32_t k_in,
+                                  int32_t hidden, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, const float* w3,
+                                  const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                  float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                  float* loss_out, float* y, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  MRI_REQUIRE(supported(k_in, hidden, 1), "tiny MLP %d -> %d -> %d -> 1 is not supported", k_in,
+              hidden, hidden);
+  MRI_REQUIRE(n >= 0 && grad_divisor > 0.f, "bad n / grad_divisor");
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && target && w1 && b1 && w2 && b2 && w3 && b3, "NULL device pointer");
+  MRI_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && loss_out, "NULL gradient pointer");
+  const int blocks = pick_blocks(hidden, n);
+  const int slab = slab_floats(hidden, k_in);
+  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)blocks * slab * 4,
+              "tiny MLP needs a workspace of %lld bytes (mri_tiny_mlp_workspace_bytes)",
+              (long long)blocks * slab * 4);
+  FusedArgs a{};
+  a.x = x, a.target = target;
+  a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3;
+  a.y = y, a.dx = d_x, a.partial = static_cast<float*>(workspace);
+  a.n = n, a.k_in = k_in;
+  a.grad_scale = (float)(2.0 / ((double)n * (double)grad_divisor));
+  a.inv_n = (float)(1.0 / (double)n);
+  if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
+  ReduceArgs r{};
+  r.partial = a.partial, r.slabs = blocks, r.slab = slab, r.n_seg = 7;
+  const int lens[7] = {hidden * k_in, hidden, hidden * hidden, hidden, hidden, 1, 1};
+  float* dsts[7] = {d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, loss_out};
+  int off = 0;
+  for (int g = 0; g < 7; ++g) {
+    r.seg_begin[g] = off, r.seg_len[g] = lens[g], r.dst[g] = dsts[g];
+    off += lens[g];
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 256)), dim3(256), 0,
+                     (hipStream_t)stream, r);
+  return check_launch("slab_reduce_kernel");
+}

@@ -252,6 +252,50 @@ def linear_act(x, weight, bias, activation=ACT_IDENTITY, w0=1.0):
     return LinearActFunction.apply(x, weight, bias, activation, w0)
 
 
+# --------------------------------------------------------------------------- fused tiny MLP
+def tiny_mlp_supported(k_in: int, hidden: int, dim_out: int) -> bool:
+    return bool(_lib.load().mri_tiny_mlp_supported(k_in, hidden, dim_out))
+
+
+_mlp_workspace = {}
+
+
+def _tiny_workspace(k_in, hidden, n, device):
+    need = _lib.load().mri_tiny_mlp_workspace_bytes(k_in, hidden, n)
+    ws = _mlp_workspace.get(device.index)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        _mlp_workspace[device.index] = ws
+    return ws
+
+
+def tiny_mlp_forward(x_fm, params, y=None):
+    """y (n, 1) = MLP(x) for feature-major x (k_in, n); params = [(w1,b1),(w2,b2),(w3,b3)]."""
+    (w1, b1), (w2, b2), (w3, b3) = params
+    _gpu(x_fm, w1, b1, w2, b2, w3, b3, y)
+    k_in, n = x_fm.shape
+    if y is None:
+        y = torch.empty((n, 1), device=x_fm.device, dtype=torch.float32)
+    _lib.call("mri_tiny_mlp_forward", _ptr(x_fm), n, k_in, w1.shape[0], _ptr(w1), _ptr(b1),
+              _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(y), _stream())
+    return y
+
+
+def tiny_mlp_train(x_fm, target, params, grads, loss_out, d_x=None, y=None,
+                   grad_divisor: float = 1.0):
+    """Forward + MSE + backward of the tiny MLP in one kernel; grads accumulate."""
+    (w1, b1), (w2, b2), (w3, b3) = params
+    (g1, gb1), (g2, gb2), (g3, gb3) = grads
+    _gpu(x_fm, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_x, y)
+    k_in, n = x_fm.shape
+    ws = _tiny_workspace(k_in, w1.shape[0], n, x_fm.device)
+    _lib.call("mri_tiny_mlp_train", _ptr(x_fm), _ptr(target), n, k_in, w1.shape[0], _ptr(w1),
+              _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor), _ptr(g1),
+              _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3), _ptr(d_x), _ptr(loss_out),
+              _ptr(y), _ptr(ws), ws.numel() * 4, _stream())
+    return loss_out
+
+
 # --------------------------------------------------------------------------- loss / optimiser
 def mse_loss(pred, target, loss_out, d_pred=None, grad_divisor: float = 1.0):
     """loss_out[0] += mean((pred - target)^2); d_pred = 2 (pred - target) / (N * divisor)."""

@@ -78,6 +78,23 @@ class FusedStep:
                         self.flat.grad_view(l.bias) if l.bias is not None else None)
                        for l in self.layers]
         self._table_grad = self.flat.grad_view(self.encoder.table) if self.encoder else None
+        self.tiny = self._tiny_mlp_plan()
+        self.use_tiny = self.tiny is not None
+
+    def _tiny_mlp_plan(self):
+        """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
+        in -> H -> H -> 1 with ReLU hidden layers, a linear output and biases everywhere."""
+        ls = self.layers
+        if self.encoder is None or len(ls) != 3 or any(l.bias is None for l in ls):
+            return None
+        if [l.activation for l in ls] != [ops.ACT_RELU, ops.ACT_RELU, ops.ACT_IDENTITY]:
+            return None
+        h, k_in = ls[0].weight.shape
+        if ls[1].weight.shape != (h, h) or ls[2].weight.shape != (1, h):
+            return None
+        if not ops.tiny_mlp_supported(k_in, h, 1):
+            return None
+        return dict(params=[(l.weight.data, l.bias.data) for l in ls], grads=self._grads)
 
     @contextlib.contextmanager
     def _phase(self, name: str):
@@ -126,6 +143,11 @@ class FusedStep:
                 x = ops.hashgrid_forward(self.encoder.desc, coords, self.encoder.table.data,
                                          out=ws["enc"], feature_major=True)
             feature_major = True
+        if self.use_tiny and not train:
+            with self._phase("mlp_fwd"):
+                return ops.tiny_mlp_forward(x, self.tiny["params"], y=ws["y"][-1]), ws
+        if self.use_tiny:
+            return x, ws  # the training kernel runs forward and backward together
         with self._phase("mlp_fwd"):
             for i, l in enumerate(self.layers):
                 deriv = ws["deriv"][i] if train else None
@@ -149,6 +171,14 @@ class FusedStep:
         with self._phase("zero_grad"):
             self.flat.grad.zero_()
             self.loss.zero_()
+        if self.use_tiny:
+            with self._phase("mlp_fused"):
+                ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"], self.tiny["grads"],
+                                   self.loss, d_x=ws["d_enc"], grad_divisor=float(self.world))
+            with self._phase("hashgrid_bwd"):
+                ops.hashgrid_backward(self.encoder.desc, coords, ws["d_enc"], self._table_grad,
+                                      feature_major=True, method=self.bwd_method)
+            return
         last = len(self.layers) - 1
         pred = ws["y"][last]
         dz = ws["dz"][last]

@@ -31,7 +31,8 @@ def test_header_symbols_are_exported(lib):
     handle = lib.load()
     for name in names:
         assert hasattr(handle, name), f"{name} declared in mri_inr.h but not exported"
-    bound = set(lib.SIGNATURES) | set(lib.STRING_GETTERS) | set(lib.INT64_GETTERS)
+    bound = (set(lib.SIGNATURES) | set(lib.STRING_GETTERS) | set(lib.INT64_GETTERS)
+             | set(lib.INT_GETTERS))
     assert bound == set(names), (bound ^ set(names))
 
 

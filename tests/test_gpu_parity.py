@@ -451,3 +451,63 @@ def test_lds_backward_is_bitwise_reproducible(amd):
     big = torch.zeros_like(enc.table.data)
     ops.hashgrid_backward(enc.desc, x, d * 1e12, big, feature_major=True, method=2)
     assert_close(big.cpu().numpy(), (runs[0] * 1e12).cpu().numpy(), 1e-5, "scale invariance")
+
+
+@pytest.mark.parametrize("k_in,hidden,n", [(32, 128, 4096), (32, 128, 1000), (32, 64, 2500),
+                                           (8, 64, 777), (64, 64, 1024), (4, 128, 65)])
+def test_tiny_mlp_fused_kernel(amd, k_in, hidden, n):
+    """One-kernel forward + MSE + backward of the in->H->H->1 ReLU MLP against the oracle
+    (torch autograd on the CPU), feature-major input and feature gradient."""
+    ops = amd.ops
+    assert ops.tiny_mlp_supported(k_in, hidden, 1)
+    params = omlp.linear_init([k_in, hidden, hidden, 1], 7 + k_in)
+    x = torch.from_numpy(detrand.uniform(n * k_in, 1, -1, 1).reshape(n, k_in)).requires_grad_(True)
+    t = torch.from_numpy(detrand.uniform(n, 2, 0, 1).reshape(n, 1))
+    flat = [p for wb in params for p in wb]
+    for p in flat:
+        p.requires_grad_(True)
+    y = omlp.relu_mlp_forward(x, params, final_activation=False)
+    loss = omlp.mse_loss(y, t)
+    loss.backward()
+
+    gp = [(w.detach().cuda(), b.detach().cuda()) for w, b in params]
+    grads = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in gp]
+    x_fm = x.detach().t().contiguous().cuda()
+    d_x = torch.empty_like(x_fm)
+    y_gpu = torch.empty(n, 1, device="cuda")
+    loss_gpu = torch.zeros(1, device="cuda")
+    ops.tiny_mlp_train(x_fm, t.cuda(), gp, grads, loss_gpu, d_x=d_x, y=y_gpu)
+    assert_close(y_gpu.cpu().numpy(), y.detach().numpy(), REL_TOL, "y")
+    assert abs(float(loss_gpu) - float(loss.detach())) <= REL_TOL * float(loss.detach())
+    assert_close(d_x.t().cpu().numpy(), x.grad.numpy(), REL_TOL, "dx")
+    for i, ((gw, gb), (w, b)) in enumerate(zip(grads, params)):
+        assert_close(gw.cpu().numpy(), w.grad.numpy(), REL_TOL, f"dW{i + 1}")
+        assert_close(gb.cpu().numpy(), b.grad.numpy(), REL_TOL, f"db{i + 1}")
+    # inference entry point, and run-to-run bitwise reproducibility of the gradients
+    assert torch.equal(ops.tiny_mlp_forward(x_fm, gp), y_gpu)
+    grads2 = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in gp]
+    ops.tiny_mlp_train(x_fm, t.cuda(), gp, grads2, torch.zeros(1, device="cuda"))
+    assert all(torch.equal(a, c) and torch.equal(b_, d) for (a, b_), (c, d) in zip(grads, grads2))
+    assert not ops.tiny_mlp_supported(64, 128, 1) and not ops.tiny_mlp_supported(32, 96, 1)
+
+
+def test_fused_step_paths_agree(amd):
+    """BASELINE config 2 model: the single-kernel MLP path and the layer-wise GEMM path give
+    the same parameters after two Adam steps."""
+    results = []
+    for use_tiny in (True, False):
+        torch.manual_seed(3)
+        net = amd.models.HashMLP(3, 16, 2, 19, 16, 512, dim_hidden=64, n_layers=3,
+                                 activation=torch.nn.ReLU, batch_norm=False,
+                                 final_activation=False, lr=5e-3).cuda()
+        step = amd.trainer.FusedStep(net, net.configure_optimizers())
+        assert step.use_tiny
+        step.use_tiny = use_tiny
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for _ in range(2):
+            x = torch.rand(20000, 3, device="cuda", generator=g)
+            y = torch.rand(20000, 1, device="cuda", generator=g)
+            loss = float(step.train_step(x, y))
+        results.append((loss, step.flat.param.clone()))
+    assert abs(results[0][0] - results[1][0]) <= REL_TOL * results[1][0]
+    assert_close(results[0][1].cpu().numpy(), results[1][1].cpu().numpy(), REL_TOL, "params")
