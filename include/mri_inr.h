@@ -94,7 +94,7 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  *   method 0 = choose per level; 1 = global float atomics; 2 = LDS owner-computes scan with
  *   64-bit fixed-point accumulation (bitwise reproducible gradients).
  *   workspace: device scratch of at least mri_hashgrid_backward_workspace_bytes(grid, n)
- *   bytes, 8-byte aligned, ZERO-INITIALISED by the caller once; every call leaves it zeroed
+ *   bytes, 16-byte aligned, ZERO-INITIALISED by the caller once; every call leaves it zeroed
  *   again, so it can be reused across steps without clearing.  May be NULL for method 1.
  */
 int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n);

@@ -13,7 +13,7 @@
 //     hashing 64x                                    -> 1.3 ms.
 // So the contributions are first ROUTED to the workgroup that owns their table slice, then
 // summed there with 64-bit integer LDS atomics:
-//   1. absmax     per-level max|d_out|  -> per-level power-of-two scale 2^e (on device)
+//   1. (in 4.)    per-level max|d_out|  -> per-level power-of-two scale 2^e (on device)
 //   2. count      histogram of contributions per bin (bin = level x slice of kAccWords/F slots)
 //   3. prefix     exclusive scan of the bin counts -> bin offsets
 //   4. scatter    recompute the corners, stage (slot, w*g[0..F)) records in LDS grouped by
@@ -57,7 +57,8 @@ struct BinPlan {
 struct Workspace {  // carved out of the caller's buffer
   uint32_t* max_bits;   // [kHeaderWords]       zero between calls
   uint32_t* cursor;     // [kMaxBins]           zero between calls
-  uint32_t* offsets;    // [kMaxBins + 1]
+  uint32_t* offsets;    // [kMaxBins + 1]       bin starts, multiples of 4 records
+  uint32_t* counts;     // [kMaxBins]           records per bin
   unsigned long long* partial;  // [ws_words]   zero between calls
   uint32_t* rec_slot;   // [records]
   float* rec_val;       // [F][records]
@@ -110,24 +111,6 @@ __device__ __forceinline__ void wave_exclusive_scan(const uint32_t* in, uint32_t
   if (lane == 63) out[count] = incl;
 }
 
-// ------------------------------------------------------------------------------ 1. absmax
-template <int F>
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ d_out, int64_t n,
-                                                     int64_t sl, int64_t sr, int64_t sf,
-                                                     uint32_t* __restrict__ max_bits) {
-  const int level = blockIdx.y;
-  const float* __restrict__ gl = d_out + (int64_t)level * sl;
-  float m = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-#pragma unroll
-    for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(gl[i * sr + f * sf]));
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  // non-negative floats order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_bits + level, __float_as_uint(m));
-}
-
 // ------------------------------------------------------------------------ 2. count / 4. scatter
 // One workgroup = (chunk of coords_per_block coordinates, level).  Both kernels walk the same
 // corners in the same way; `SCATTER` selects what is done with them.
@@ -136,11 +119,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
     const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
     uint32_t* __restrict__ cursor, uint32_t* __restrict__ rec_slot, float* __restrict__ rec_val,
-    int64_t records) {
+    int64_t records, uint32_t* __restrict__ max_bits) {
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
   __shared__ uint32_t stage[SCATTER ? kStageWords : 1];
+  __shared__ uint32_t wg_max;
 
   const int e = blockIdx.y;
   const int level = plan.level_of[e];
@@ -153,6 +137,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   const int64_t i_end = min(n, i_begin + plan.coords_per_block);
 
   for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
+  if (threadIdx.x == 0) wg_max = 0u;
   __syncthreads();
 
   // pass A: histogram of the corners' bins
@@ -188,11 +173,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
   const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
   for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
     const Cell<D> c = locate<D>(x, i, res);
     float g[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) g[f] = gl[i * sr + f * sf];
+    for (int f = 0; f < F; ++f) {
+      g[f] = gl[i * sr + f * sf];
+      gmax = fmaxf(gmax, fabsf(g[f]));
+    }
 #pragma unroll
     for (int nb = 0; nb < (1 << D); ++nb) {
       uint32_t h;
@@ -206,7 +195,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
     }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
+  // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
+  // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
+  if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
   __syncthreads();
+  if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(max_bits + level, wg_max);
 
   // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -226,13 +223,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
 // Bin counts (in `cursor`) -> exclusive offsets; `cursor` then holds each bin's write cursor.
 __global__ __launch_bounds__(1024) void bin_prefix_kernel(uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ offsets,
+                                                          uint32_t* __restrict__ counts,
                                                           int total_bins) {
   __shared__ uint32_t chunk_sum[1024];
   __shared__ uint32_t chunk_off[1025];
   const int per = (total_bins + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(total_bins, lo + per);
   uint32_t s = 0;
-  for (int b = lo; b < hi; ++b) s += cursor[b];
+  for (int b = lo; b < hi; ++b) s += (cursor[b] + 3u) & ~3u;  // bins start on 16-byte boundaries
   chunk_sum[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < 64) wave_exclusive_scan<16>(chunk_sum, chunk_off, 1024);
@@ -241,8 +239,9 @@ __global__ __launch_bounds__(1024) void bin_prefix_kernel(uint32_t* __restrict__
   for (int b = lo; b < hi; ++b) {
     const uint32_t v = cursor[b];
     offsets[b] = run;
+    counts[b] = v;
     cursor[b] = run;
-    run += v;
+    run += (v + 3u) & ~3u;
   }
   if (threadIdx.x == 0) offsets[total_bins] = chunk_off[1024];
 }
@@ -251,7 +250,8 @@ __global__ __launch_bounds__(1024) void bin_prefix_kernel(uint32_t* __restrict__
 template <int F>
 __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ rec_slot, const float* __restrict__ rec_val, int64_t records,
+    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_slot,
+    const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
     unsigned long long* __restrict__ partial) {
   __shared__ unsigned long long acc[kAccWords];
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   const uint32_t base = (uint32_t)part * slots;
   const uint32_t count = min(slots, tab.size[level] - base);
   const int bin = plan.bin_start[e] + part;
-  const uint32_t r_lo = offsets[bin], r_cnt = offsets[bin + 1] - r_lo;
-  const uint32_t per = (r_cnt + splits - 1) / splits;
+  const uint32_t r_lo = offsets[bin], r_cnt = counts[bin];  // r_lo is a multiple of 4
+  const uint32_t per = ((r_cnt + splits - 1) / splits + 3u) & ~3u;
   const uint32_t k_lo = min(r_cnt, (uint32_t)split * per), k_hi = min(r_cnt, k_lo + per);
   if (k_lo >= k_hi) return;  // nothing routed here (uniform for the workgroup)
 
@@ -274,13 +274,26 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  for (uint32_t k = k_lo + threadIdx.x; k < k_hi; k += kAccThreads) {
-    const uint32_t rel = rec_slot[(uint64_t)r_lo + k];
+  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4)
+  const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
+  for (uint32_t k = k_lo + 4 * threadIdx.x; k < k_vec; k += 4 * kAccThreads) {
+    const uint4 rel = *reinterpret_cast<const uint4*>(rec_slot + (uint64_t)r_lo + k);
+    const uint32_t r4[4] = {rel.x, rel.y, rel.z, rel.w};
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      const float v = rec_val[(uint64_t)f * records + r_lo + k];
-      atomicAdd(&acc[rel * F + f], (unsigned long long)to_fixed(v, scale_hi));
+      const float4 v = *reinterpret_cast<const float4*>(rec_val + (uint64_t)f * records + r_lo + k);
+      const float v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
     }
+  }
+  for (uint32_t k = k_vec + threadIdx.x; k < k_hi; k += kAccThreads) {
+    const uint32_t rel = rec_slot[(uint64_t)r_lo + k];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      atomicAdd(&acc[rel * F + f],
+                (unsigned long long)to_fixed(rec_val[(uint64_t)f * records + r_lo + k], scale_hi));
   }
   __syncthreads();
   const int64_t ws_off = plan.ws_offset[e];
@@ -371,11 +384,12 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uin
     }
     records += n << D;
   }
+  records = (records + 4 * (int64_t)plan.total_bins + 3) / 4 * 4;  // bins are padded to 4 records
   return plan.n_entries > 0;
 }
 
 int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
-  return (int64_t)kHeaderWords * 4 + (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 4 +
+  return (int64_t)kHeaderWords * 4 + 2 * (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 12 +
          ws_words * 8 + records * 4 * (1 + F) + 64;
 }
 
@@ -387,7 +401,9 @@ Workspace carve(void* base, int64_t ws_words, int64_t records, int F) {
   w.cursor = reinterpret_cast<uint32_t*>(p);
   p += (int64_t)kMaxBins * 4;
   w.offsets = reinterpret_cast<uint32_t*>(p);
-  p += (int64_t)(kMaxBins + 1) * 4 + 4;  // keeps the next field 8-byte aligned
+  p += (int64_t)(kMaxBins + 1) * 4 + 12;  // keeps the following fields 16-byte aligned
+  w.counts = reinterpret_cast<uint32_t*>(p);
+  p += (int64_t)kMaxBins * 4;
   w.partial = reinterpret_cast<unsigned long long*>(p);
   p += ws_words * 8;
   w.rec_slot = reinterpret_cast<uint32_t*>(p);
@@ -404,19 +420,17 @@ struct BinnedLaunch {
                  int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
     if constexpr (D <= 4 && F <= 4) {
       const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
-      hipLaunchKernelGGL((absmax_kernel<F>), dim3(64, n_levels), dim3(256), 0, st, d_out, n, sl,
-                         sr, sf, w.max_bits);
       hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
-                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records);
+                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
-                         plan.total_bins);
+                         w.counts, plan.total_bins);
       hipLaunchKernelGGL((bin_kernel<D, F, true>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
-                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records);
+                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
-                         dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.rec_slot, w.rec_val,
-                         w.records, w.max_bits, d_table, w.partial);
+                         dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.counts, w.rec_slot,
+                         w.rec_val, w.records, w.max_bits, d_table, w.partial);
       if (any_split)
-        hipLaunchKernelGGL(bin_finalize_kernel, dim3(64, plan.n_entries), dim3(256), 0, st, tab,
+        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, plan.n_entries), dim3(256), 0, st, tab,
                            plan, F, n, d_table, w.max_bits, w.partial);
       hipLaunchKernelGGL(bin_reset_kernel, dim3((unsigned)ceil_div(kMaxBins, 256)), dim3(256), 0,
                          st, w.max_bits, w.cursor, plan.total_bins);
@@ -464,8 +478,8 @@ extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
                 "hashgrid backward needs a workspace of %lld bytes "
                 "(mri_hashgrid_backward_workspace_bytes), got %lld",
                 (long long)need, (long long)workspace_bytes_given);
-    MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
-                "workspace must be 8-byte aligned");
+    MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                "workspace must be 16-byte aligned");
     const Workspace w = carve(workspace, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, w, grid->n_levels, acc_blocks,

@@ -366,10 +366,30 @@ struct ReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceArgs r) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= r.slab) return;
+  // 64 elements per workgroup; 4 thread groups each sum a quarter of the slabs (8 loads in
+  // flight), then the quarters are added in a fixed order -> same bits every run.
+  __shared__ float quarter[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int per = (r.slabs + 3) / 4;
+  const int b_lo = grp * per, b_hi = min(r.slabs, b_lo + per);
   float s = 0.f;
-  for (int b = 0; b < r.slabs; ++b) s += r.partial[(int64_t)b * r.slab + e];
+  if (e < r.slab) {
+    const float* p = r.partial + e;
+    int b = b_lo;
+    for (; b + 8 <= b_hi; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(b + j) * r.slab];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; b < b_hi; ++b) s += p[(int64_t)b * r.slab];
+  }
+  quarter[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp != 0 || e >= r.slab) return;
+  s = ((quarter[0][threadIdx.x] + quarter[1][threadIdx.x]) + quarter[2][threadIdx.x]) +
+      quarter[3][threadIdx.x];
 #pragma unroll
   for (int g = 0; g < 8; ++g)
     if (g < r.n_seg && e >= r.seg_begin[g] && e < r.seg_begin[g] + r.seg_len[g])
@@ -468,7 +488,7 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
     r.seg_begin[g] = off, r.seg_len[g] = lens[g], r.dst[g] = dsts[g];
     off += lens[g];
   }
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 64)), dim3(256), 0,
                      (hipStream_t)stream, r);
   return check_launch("slab_reduce_kernel");
 }
