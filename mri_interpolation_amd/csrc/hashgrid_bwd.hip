@@ -35,8 +35,8 @@ namespace {
 
 constexpr int kAccWords = 16384;  // 128 KiB of u64 accumulators per accumulate workgroup
 constexpr int kAccThreads = 1024;
-constexpr int kStageWords = 24576;  // 96 KiB LDS staging buffer of the scatter kernel
-constexpr int kBinThreads = 1024;
+constexpr int kStageWords = 12288;  // 48 KiB LDS staging buffer of the scatter kernel (2 workgroups/CU)
+constexpr int kBinThreads = 512;
 constexpr int kMaxParts = 256;        // slices per level handled by the binned path
 constexpr int kHeaderWords = 64;      // per-level max|g| bits
 constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
@@ -274,26 +274,48 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4)
+  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4);
+  // the next group's loads are issued before the current group's LDS atomics
   const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
-  for (uint32_t k = k_lo + 4 * threadIdx.x; k < k_vec; k += 4 * kAccThreads) {
-    const uint4 rel = *reinterpret_cast<const uint4*>(rec_slot + (uint64_t)r_lo + k);
+  const uint32_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
+  const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
+  uint32_t k = k_lo + 4 * threadIdx.x;
+  uint4 rel = make_uint4(0, 0, 0, 0);
+  float4 val[F];
+  if (k < k_vec) {
+    rel = *reinterpret_cast<const uint4*>(slot_ptr + k);
+#pragma unroll
+    for (int f = 0; f < F; ++f) val[f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k);
+  }
+  while (k < k_vec) {
+    const uint32_t k_next = k + 4 * kAccThreads;
+    uint4 rel_n = make_uint4(0, 0, 0, 0);
+    float4 val_n[F];
+    if (k_next < k_vec) {
+      rel_n = *reinterpret_cast<const uint4*>(slot_ptr + k_next);
+#pragma unroll
+      for (int f = 0; f < F; ++f)
+        val_n[f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k_next);
+    }
     const uint32_t r4[4] = {rel.x, rel.y, rel.z, rel.w};
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      const float4 v = *reinterpret_cast<const float4*>(rec_val + (uint64_t)f * records + r_lo + k);
-      const float v4[4] = {v.x, v.y, v.z, v.w};
+      const float v4[4] = {val[f].x, val[f].y, val[f].z, val[f].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
     }
+    rel = rel_n;
+#pragma unroll
+    for (int f = 0; f < F; ++f) val[f] = val_n[f];
+    k = k_next;
   }
-  for (uint32_t k = k_vec + threadIdx.x; k < k_hi; k += kAccThreads) {
-    const uint32_t rel = rec_slot[(uint64_t)r_lo + k];
+  for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) {
+    const uint32_t rel_t = slot_ptr[kt];
 #pragma unroll
     for (int f = 0; f < F; ++f)
-      atomicAdd(&acc[rel * F + f],
-                (unsigned long long)to_fixed(rec_val[(uint64_t)f * records + r_lo + k], scale_hi));
+      atomicAdd(&acc[rel_t * F + f],
+                (unsigned long long)to_fixed(val_ptr[(uint64_t)f * records + kt], scale_hi));
   }
   __syncthreads();
   const int64_t ws_off = plan.ws_offset[e];
@@ -354,7 +376,7 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uin
   const int slots = kAccWords / F;
   plan.log2_slots = 31 - __builtin_clz((unsigned)slots);
   const int per_coord = (1 + F) << D;  // staging words per coordinate
-  plan.coords_per_block = std::min(1024, kStageWords / per_coord / 64 * 64);
+  plan.coords_per_block = std::min(512, kStageWords / per_coord / 64 * 64);
   const bool supported = D <= 4 && F <= 4 && plan.coords_per_block >= 64;
   const int target = options().bwd_blocks_per_level;
   for (int l = 0; l < g->n_levels; ++l) {

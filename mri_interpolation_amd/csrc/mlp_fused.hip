@@ -142,28 +142,45 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
   const int w1_ob = NB == 4 ? wave : (KB32 == 2 ? (wave >> 1) : wave);
   const int w1_kb = NB == 4 ? 0 : (KB32 == 2 ? (wave & 1) : 0);
 
+  // x tile: KP x 64 floats = KP * 16 float4 pieces, XV per thread, fetched one tile ahead into
+  // registers (feature-major rows are contiguous along the batch)
+  constexpr int XV = KP * (kTile / 4) / kThreads;
+  static_assert(XV * kThreads == KP * (kTile / 4), "x tile must divide over the workgroup");
+  auto load_x = [&](int64_t m0, float4 (&v)[XV]) {
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int e = tid + j * kThreads;
+      const int k = e / (kTile / 4), c4 = (e % (kTile / 4)) * 4;
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < a.k_in && m0 + c4 < a.n) {
+        const float* src = a.x + (int64_t)k * a.n + m0 + c4;
+        if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+          v[j] = *reinterpret_cast<const float4*>(src);
+        } else {
+          v[j].x = src[0];
+          if (m0 + c4 + 1 < a.n) v[j].y = src[1];
+          if (m0 + c4 + 2 < a.n) v[j].z = src[2];
+          if (m0 + c4 + 3 < a.n) v[j].w = src[3];
+        }
+      }
+    }
+  };
   const int64_t tiles = (a.n + kTile - 1) / kTile;
+  float4 x_next[XV];
+  if ((int64_t)blockIdx.x < tiles) load_x((int64_t)blockIdx.x * kTile, x_next);
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t m0 = t * kTile;
     __syncthreads();  // B0: previous tile is done with xs / h1 / h2
-    // ---- stage x tile: xs[c][k] from feature-major x[k][m0 + c] -----------------------------
-    for (int e = tid; e < KP * (kTile / 4); e += kThreads) {
+    // ---- stage x tile: xs[c][k] from the prefetched registers, then fetch the next tile -------
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+      const int e = tid + j * kThreads;
       const int k = e / (kTile / 4), c4 = (e % (kTile / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < a.k_in) {
-        const float* src = a.x + (int64_t)k * a.n + m0 + c4;
-        if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (m0 + c4 + 0 < a.n) v.x = src[0];
-          if (m0 + c4 + 1 < a.n) v.y = src[1];
-          if (m0 + c4 + 2 < a.n) v.z = src[2];
-          if (m0 + c4 + 3 < a.n) v.w = src[3];
-        }
-      }
       float* dst = sm.xs + c4 * S::ldx + k;
-      dst[0] = v.x, dst[S::ldx] = v.y, dst[2 * S::ldx] = v.z, dst[3 * S::ldx] = v.w;
+      dst[0] = x_next[j].x, dst[S::ldx] = x_next[j].y, dst[2 * S::ldx] = x_next[j].z,
+      dst[3 * S::ldx] = x_next[j].w;
     }
+    if (t + gridDim.x < tiles) load_x((t + gridDim.x) * kTile, x_next);
     __syncthreads();  // B1
 
     // ---- layer 1: h1 = relu(x W1^T + b1) -----------------------------------------------------

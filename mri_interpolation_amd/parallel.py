@@ -80,6 +80,22 @@ def all_reduce_sum(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def all_reduce_async(flat: torch.Tensor):
+    """Start an in-place sum over ranks of a contiguous gradient slice; returns a handle for
+    wait_all().  With the RCCL backend the collective runs on the process group's own stream,
+    ordered after the work already queued on the current stream, so later kernels overlap it."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def wait_all(handles):
+    """Make the current stream (or the host, for gloo) wait for the pending reductions."""
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 def all_reduce_max(value: float, device) -> float:
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return value

@@ -80,6 +80,11 @@ class FusedStep:
         self._table_grad = self.flat.grad_view(self.encoder.table) if self.encoder else None
         self.tiny = self._tiny_mlp_plan()
         self.use_tiny = self.tiny is not None
+        # Data parallel: the table gradient is produced level by level, so its reduction is cut
+        # into `grad_buckets` level groups; group g's all-reduce (RCCL, its own stream) runs
+        # while group g+1's gradient is still being computed.  1 = one reduction at the end.
+        self.grad_buckets = 1 if world == 1 else 4
+        self._bucket_cache = None
 
     def _tiny_mlp_plan(self):
         """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
@@ -158,6 +163,43 @@ class FusedStep:
                 feature_major = False
         return x, ws
 
+    def _level_buckets(self, n: int):
+        """[(sub-descriptor, first level, flat-gradient slice)] for the current bucket count."""
+        enc = self.encoder
+        key = (self.grad_buckets, n)
+        if self._bucket_cache is not None and self._bucket_cache[0] == key:
+            return self._bucket_cache[1]
+        groups = max(1, min(self.grad_buckets, enc.n_levels))
+        bounds = [round(g * enc.n_levels / groups) for g in range(groups + 1)]
+        table_off = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
+                                           if q is enc.table)]
+        out = []
+        for lo, hi in zip(bounds, bounds[1:]):
+            desc = ops.make_grid_desc(enc.dim, enc.resolutions[lo:hi], enc.sizes[lo:hi],
+                                      enc.n_features_per_level)
+            row_lo, row_hi = enc._row_span(lo)[0], enc._row_span(hi - 1)[1]
+            for l in range(hi - lo):  # offsets stay absolute: the gradient base pointer is shared
+                desc.table_offset[l] = enc._row_span(lo + l)[0]
+            f = enc.n_features_per_level
+            out.append((desc, lo, self.flat.grad[table_off + row_lo * f:table_off + row_hi * f]))
+        self._bucket_cache = (key, out)
+        return out
+
+    def _hash_backward(self, coords, d_enc):
+        """Table gradient; with several ranks, reduce each finished level group right away."""
+        enc, n = self.encoder, coords.shape[0]
+        if self.world == 1 or self.grad_buckets <= 1:
+            ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
+                                  method=self.bwd_method)
+            return []
+        pending = []
+        rows_per_level = enc.n_features_per_level
+        for desc, first, grad_slice in self._level_buckets(n):
+            ops.hashgrid_backward(desc, coords, d_enc[first * rows_per_level:], self._table_grad,
+                                  feature_major=True, method=self.bwd_method)
+            pending.append(parallel.all_reduce_async(grad_slice))
+        return pending
+
     def _deriv_of(self, i, ws):
         mode = ops.deriv_mode_for(self.layers[i].activation)
         if mode == ops.DERIV_MUL:
@@ -176,8 +218,7 @@ class FusedStep:
                 ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"], self.tiny["grads"],
                                    self.loss, d_x=ws["d_enc"], grad_divisor=float(self.world))
             with self._phase("hashgrid_bwd"):
-                ops.hashgrid_backward(self.encoder.desc, coords, ws["d_enc"], self._table_grad,
-                                      feature_major=True, method=self.bwd_method)
+                self._pending = self._hash_backward(coords, ws["d_enc"])
             return
         last = len(self.layers) - 1
         pred = ws["y"][last]
@@ -202,16 +243,27 @@ class FusedStep:
                                              dx=ws["d_enc"], dx_feature_major=True)
         if self.encoder is not None:
             with self._phase("hashgrid_bwd"):
-                ops.hashgrid_backward(self.encoder.desc, coords, ws["d_enc"], self._table_grad,
-                                      feature_major=True, method=self.bwd_method)
+                self._pending = self._hash_backward(coords, ws["d_enc"])
 
     def train_step(self, coords, target) -> torch.Tensor:
         """One optimisation step; returns the (device) loss scalar of this rank's batch."""
         _, ws = self.forward(coords, train=True)
+        self._pending = []
         self.backward(coords, target, ws)
         if self.world > 1:
             with self._phase("all_reduce"):
-                parallel.all_reduce_sum(self.flat.grad)
+                if self._pending:  # table levels are already in flight: add everything else
+                    f = self.encoder.n_features_per_level
+                    t0 = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
+                                                if q is self.encoder.table)]
+                    t1 = t0 + self.encoder.table.shape[0] * f
+                    if t0 > 0:
+                        self._pending.append(parallel.all_reduce_async(self.flat.grad[:t0]))
+                    if t1 < self.flat.numel:
+                        self._pending.append(parallel.all_reduce_async(self.flat.grad[t1:]))
+                    parallel.wait_all(self._pending)
+                else:
+                    parallel.all_reduce_sum(self.flat.grad)
         with self._phase("adam"):
             self.opt.step()
         return self.loss

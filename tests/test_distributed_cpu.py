@@ -48,7 +48,12 @@ def _worker(rank, world, port, out_dir):
         x, y = _batch(rank + 10 * step)
         _, _, grads = otrain.loss_and_grads(model, x, y)
         flat = torch.cat([g.reshape(-1) for g in grads]) / world  # pre-averaged, as the loss kernel does
-        parallel.all_reduce_sum(flat)
+        if step == 1:  # bucketed, asynchronous form used to overlap with the hash-grid backward
+            cut = flat.numel() // 3
+            parallel.wait_all([parallel.all_reduce_async(flat[:cut]),
+                               parallel.all_reduce_async(flat[cut:])])
+        else:
+            parallel.all_reduce_sum(flat)
         off, synced = 0, []
         for g in grads:
             synced.append(flat[off:off + g.numel()].view_as(g))

@@ -511,3 +511,27 @@ def test_fused_step_paths_agree(amd):
         results.append((loss, step.flat.param.clone()))
     assert abs(results[0][0] - results[1][0]) <= REL_TOL * results[1][0]
     assert_close(results[0][1].cpu().numpy(), results[1][1].cpu().numpy(), REL_TOL, "params")
+
+
+def test_bucketed_backward_equals_single_launch(amd):
+    """Data-parallel mode computes the table gradient in level groups (so that each group's
+    all-reduce can start early): same bits as the single launch."""
+    torch.manual_seed(2)
+    net = amd.models.HashMLP(3, 16, 2, 19, 16, 512, dim_hidden=64, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False,
+                             final_activation=False).cuda()
+    with torch.no_grad():
+        net.encoder.table.uniform_(-0.5, 0.5)
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    x = torch.rand(30000, 3, device="cuda")
+    y = torch.rand(30000, 1, device="cuda")
+    _, ws = step.forward(x, train=True)
+    step.backward(x, y, ws)
+    want = step.flat.grad.clone()
+    step.world, step.grad_buckets = 2, 4          # bucketed path; no process group -> no-op reductions
+    step._pending = []
+    step.backward(x, y, ws)
+    assert len(step._pending) == 4 and torch.equal(step.flat.grad, want)
+    step.grad_buckets = 3
+    step.backward(x, y, ws)
+    assert len(step._pending) == 3 and torch.equal(step.flat.grad, want)
