@@ -94,8 +94,10 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  *   method 0 = choose per level; 1 = global float atomics; 2 = LDS owner-computes scan with
  *   64-bit fixed-point accumulation (bitwise reproducible gradients).
  *   workspace: device scratch of at least mri_hashgrid_backward_workspace_bytes(grid, n)
- *   bytes, 16-byte aligned, ZERO-INITIALISED by the caller once; every call leaves it zeroed
- *   again, so it can be reused across steps without clearing.  May be NULL for method 1.
+ *   bytes, 16-byte aligned, ZERO-INITIALISED by the caller once; every call hands its
+ *   zero-between-calls regions back zeroed, so it can be reused across steps without clearing.
+ *   A buffer shared by calls with different grids / n must be sized for the largest of them
+ *   and always be passed with the same workspace_bytes.  May be NULL for method 1.
  */
 int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n);
 int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x, const float* d_out,

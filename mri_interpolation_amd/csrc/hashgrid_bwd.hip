@@ -415,7 +415,11 @@ int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
          ws_words * 8 + records * 4 * (1 + F) + 64;
 }
 
-Workspace carve(void* base, int64_t ws_words, int64_t records, int F) {
+// Fixed-position regions first, the record area next, and the zero-between-calls int64 area
+// anchored at the END of the caller's buffer: calls with different level sets / batch sizes that
+// share one buffer (of one size) then always find their int64 area inside memory that only ever
+// holds int64 partial sums, never another call's records.
+Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t records, int F) {
   Workspace w{};
   char* p = static_cast<char*>(base);
   w.max_bits = reinterpret_cast<uint32_t*>(p);
@@ -426,12 +430,12 @@ Workspace carve(void* base, int64_t ws_words, int64_t records, int F) {
   p += (int64_t)(kMaxBins + 1) * 4 + 12;  // keeps the following fields 16-byte aligned
   w.counts = reinterpret_cast<uint32_t*>(p);
   p += (int64_t)kMaxBins * 4;
-  w.partial = reinterpret_cast<unsigned long long*>(p);
-  p += ws_words * 8;
   w.rec_slot = reinterpret_cast<uint32_t*>(p);
   p += records * 4;
   w.rec_val = reinterpret_cast<float*>(p);
   w.records = records;
+  const int64_t tail = (total_bytes - ws_words * 8) & ~int64_t(15);
+  w.partial = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + tail);
   return w;
 }
 
@@ -502,7 +506,7 @@ extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
                 (long long)need, (long long)workspace_bytes_given);
     MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                 "workspace must be 16-byte aligned");
-    const Workspace w = carve(workspace, ws_words, records, F);
+    const Workspace w = carve(workspace, workspace_bytes_given, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, w, grid->n_levels, acc_blocks,
                                     ws_words > 0, x, d_out, n, dout_level_stride, dout_row_stride,
