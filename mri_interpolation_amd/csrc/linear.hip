@@ -14,8 +14,10 @@
 //                                                                    split over blockIdx.z, f32 atomics)
 // A 256-thread workgroup (4 waves) owns a BI x BJ tile; each wave owns TI x TJ MFMA tiles of
 // 32x32 and keeps them in registers across the contraction loop.  Both operand tiles are
-// staged through LDS in 32-deep chunks, in whichever of two images makes the staging stores
-// and the fragment reads conflict-free for that operand's memory order:
+// staged through LDS in 32-deep chunks -- two LDS stages, global loads of chunk c+1 issued into
+// registers before the MFMAs of chunk c and written to the other stage after them, one barrier
+// per chunk -- in whichever of two images makes the staging stores and the fragment reads
+// conflict-free for that operand's memory order:
 //   "row" image  [o][c], leading dim 33   (operand contiguous along the contraction)
 //   "col" image  [c][o], leading dim O+4  (operand contiguous along the outer index)
 #include <math.h>
@@ -67,58 +69,96 @@ struct TileImage {
   static constexpr int kFloats = (O * kRowLd > KB * kColLd) ? O * kRowLd : KB * kColLd;
 };
 
-// Fill one operand tile (O outer x KB contraction) of LDS, zero-filling out-of-range elements.
+// An operand tile is O (outer) x KB (contraction) floats = O*KB/256 per thread.  It travels in two
+// halves so that the global loads of chunk c+1 are in flight while chunk c is on the MFMAs:
+//   load_tile   global -> registers (zero-filling out-of-range elements)
+//   store_tile  registers -> LDS image
 template <int O>
-__device__ __forceinline__ void stage(float* __restrict__ lds, const Operand& op, int64_t o0,
-                                      int64_t o_end, int64_t c0, int64_t c_end) {
+struct TileRegs {
+  static constexpr int kPer = O * KB / kThreads;  // floats per thread
+  float v[kPer];
+};
+
+template <int O>
+__device__ __forceinline__ void load_tile(TileRegs<O>& r, const Operand& op, int64_t o0,
+                                          int64_t o_end, int64_t c0, int64_t c_end) {
   const int t = threadIdx.x;
-  if (op.mode == 1) {
-    constexpr int kVec = O * (KB / 4);
+  constexpr int kPer = TileRegs<O>::kPer;
+  if (op.mode == 1) {  // float4 along the contraction
 #pragma unroll
-    for (int v = t; v < kVec; v += kThreads) {
+    for (int q = 0; q < kPer / 4; ++q) {
+      const int v = t + q * kThreads;
       const int o = v / (KB / 4), c4 = (v % (KB / 4)) * 4;
       const int64_t go = o0 + o, gc = c0 + c4;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (go < o_end) {
         const float* src = op.ptr + go * op.os + gc;
         if (gc + 3 < c_end) {
-          r = *reinterpret_cast<const float4*>(src);
+          x = *reinterpret_cast<const float4*>(src);
         } else {
-          if (gc + 0 < c_end) r.x = src[0];
-          if (gc + 1 < c_end) r.y = src[1];
-          if (gc + 2 < c_end) r.z = src[2];
+          if (gc + 0 < c_end) x.x = src[0];
+          if (gc + 1 < c_end) x.y = src[1];
+          if (gc + 2 < c_end) x.z = src[2];
         }
       }
-      float* dst = lds + o * TileImage<O>::kRowLd + c4;
-      dst[0] = r.x, dst[1] = r.y, dst[2] = r.z, dst[3] = r.w;
+      r.v[4 * q] = x.x, r.v[4 * q + 1] = x.y, r.v[4 * q + 2] = x.z, r.v[4 * q + 3] = x.w;
     }
-  } else if (op.mode == 2) {
-    constexpr int kVec = (O / 4) * KB;
+  } else if (op.mode == 2) {  // float4 along the outer index
 #pragma unroll
-    for (int v = t; v < kVec; v += kThreads) {
+    for (int q = 0; q < kPer / 4; ++q) {
+      const int v = t + q * kThreads;
       const int c = v / (O / 4), o4 = (v % (O / 4)) * 4;
       const int64_t go = o0 + o4, gc = c0 + c;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gc < c_end) {
         const float* src = op.ptr + gc * op.cs + go;
         if (go + 3 < o_end) {
-          r = *reinterpret_cast<const float4*>(src);
+          x = *reinterpret_cast<const float4*>(src);
         } else {
-          if (go + 0 < o_end) r.x = src[0];
-          if (go + 1 < o_end) r.y = src[1];
-          if (go + 2 < o_end) r.z = src[2];
+          if (go + 0 < o_end) x.x = src[0];
+          if (go + 1 < o_end) x.y = src[1];
+          if (go + 2 < o_end) x.z = src[2];
         }
       }
-      *reinterpret_cast<float4*>(lds + c * TileImage<O>::kColLd + o4) = r;
+      r.v[4 * q] = x.x, r.v[4 * q + 1] = x.y, r.v[4 * q + 2] = x.z, r.v[4 * q + 3] = x.w;
     }
   } else {
-    constexpr int kElems = O * KB;
-    for (int v = t; v < kElems; v += kThreads) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int v = t + q * kThreads;
       const int o = v / KB, c = v % KB;
       const int64_t go = o0 + o, gc = c0 + c;
-      float r = 0.f;
-      if (go < o_end && gc < c_end) r = op.ptr[go * op.os + gc * op.cs];
-      lds[o * TileImage<O>::kRowLd + c] = r;
+      r.v[q] = (go < o_end && gc < c_end) ? op.ptr[go * op.os + gc * op.cs] : 0.f;
+    }
+  }
+}
+
+template <int O>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const TileRegs<O>& r,
+                                           int mode) {
+  const int t = threadIdx.x;
+  constexpr int kPer = TileRegs<O>::kPer;
+  if (mode == 1) {
+#pragma unroll
+    for (int q = 0; q < kPer / 4; ++q) {
+      const int v = t + q * kThreads;
+      const int o = v / (KB / 4), c4 = (v % (KB / 4)) * 4;
+      float* dst = lds + o * TileImage<O>::kRowLd + c4;
+      dst[0] = r.v[4 * q], dst[1] = r.v[4 * q + 1], dst[2] = r.v[4 * q + 2], dst[3] = r.v[4 * q + 3];
+    }
+  } else if (mode == 2) {
+#pragma unroll
+    for (int q = 0; q < kPer / 4; ++q) {
+      const int v = t + q * kThreads;
+      const int c = v / (O / 4), o4 = (v % (O / 4)) * 4;
+      *reinterpret_cast<float4*>(lds + c * TileImage<O>::kColLd + o4) =
+          make_float4(r.v[4 * q], r.v[4 * q + 1], r.v[4 * q + 2], r.v[4 * q + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int v = t + q * kThreads;
+      lds[(v / KB) * TileImage<O>::kRowLd + (v % KB)] = r.v[q];
     }
   }
 }
@@ -133,12 +173,11 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
 }
 
 template <int WI, int WJ, int TI, int TJ, int EPI>
-__global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
   static_assert(WI * WJ * kWave == kThreads, "4 waves per workgroup");
-  __shared__ float lds[TileImage<BI>::kFloats + TileImage<BJ>::kFloats];
-  float* __restrict__ ps = lds;
-  float* __restrict__ qs = lds + TileImage<BI>::kFloats;
+  constexpr int kStage = TileImage<BI>::kFloats + TileImage<BJ>::kFloats;
+  __shared__ float lds[2 * kStage];  // two stages: chunk c is read while chunk c+1 is written
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
@@ -152,8 +191,8 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs a) {
   const int p_sc = a.p.mode == 2 ? TileImage<BI>::kColLd : 1;
   const int q_so = a.q.mode == 2 ? 1 : TileImage<BJ>::kRowLd;
   const int q_sc = a.q.mode == 2 ? TileImage<BJ>::kColLd : 1;
-  const float* __restrict__ pf = ps + (wi * TI * 32 + l31) * p_so + lh * p_sc;
-  const float* __restrict__ qf = qs + (wj * TJ * 32 + l31) * q_so + lh * q_sc;
+  const int pf_off = (wi * TI * 32 + l31) * p_so + lh * p_sc;
+  const int qf_off = TileImage<BI>::kFloats + (wj * TJ * 32 + l31) * q_so + lh * q_sc;
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -166,14 +205,29 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs a) {
   float rowsum = 0.f;
   const bool want_rowsum = EPI == EPI_ATOMIC && a.rowsum_out != nullptr && blockIdx.y == 0;
 
+  TileRegs<BI> pr;
+  TileRegs<BJ> qr;
+  if (c_begin < c_end) {
+    load_tile<BI>(pr, a.p, i0, a.I, c_begin, c_end);
+    load_tile<BJ>(qr, a.q, j0, a.J, c_begin, c_end);
+    store_tile<BI>(lds, pr, a.p.mode);
+    store_tile<BJ>(lds + TileImage<BI>::kFloats, qr, a.q.mode);
+  }
+  __syncthreads();
+  int stage_id = 0;
   for (int64_t c0 = c_begin; c0 < c_end; c0 += KB) {
-    __syncthreads();
-    stage<BI>(ps, a.p, i0, a.I, c0, c_end);
-    stage<BJ>(qs, a.q, j0, a.J, c0, c_end);
-    __syncthreads();
+    const float* __restrict__ cur = lds + stage_id * kStage;
+    float* __restrict__ nxt = lds + (stage_id ^ 1) * kStage;
+    const bool more = c0 + KB < c_end;
+    if (more) {  // global loads of the next chunk fly while this chunk is on the matrix cores
+      load_tile<BI>(pr, a.p, i0, a.I, c0 + KB, c_end);
+      load_tile<BJ>(qr, a.q, j0, a.J, c0 + KB, c_end);
+    }
+    const float* __restrict__ pf = cur + pf_off;
+    const float* __restrict__ qf = cur + qf_off;
     const int kc = (int)min((int64_t)KB, c_end - c0);
     if (want_rowsum && threadIdx.x < BI) {
-      const float* row = ps + threadIdx.x * p_so;
+      const float* row = cur + threadIdx.x * p_so;
       for (int c = 0; c < kc; ++c) rowsum += row[c * p_sc];
     }
     auto mfma_steps = [&](const int k_lo, const int k_hi) {
@@ -194,9 +248,15 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs a) {
     };
     if (kc == KB) {
       mfma_steps(0, KB);
-    } else {  // ragged tail of the contraction (zero-filled by stage): stop at the last pair
+    } else {  // ragged tail of the contraction (zero-filled by load_tile): stop at the last pair
       for (int kk = 0; kk < kc; kk += 2) mfma_steps(kk, kk + 2);
     }
+    if (more) {
+      store_tile<BI>(nxt, pr, a.p.mode);
+      store_tile<BJ>(nxt + TileImage<BI>::kFloats, qr, a.q.mode);
+    }
+    __syncthreads();  // next stage complete, and everyone is done reading the current one
+    stage_id ^= 1;
   }
 
   // ---- epilogue: C/D layout of the 32x32 f32 MFMA: col = lane & 31,
