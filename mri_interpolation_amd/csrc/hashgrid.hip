@@ -67,25 +67,51 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+  if constexpr (F == 2) {
+    // The two corners that differ only on axis 0 (PRIME_0 = 1) hash to h and h ^ (x ^ (x+1)):
+    // for an even cell index the slots are 2k and 2k+1, i.e. one aligned 16-byte pair of rows.
+    // The kernel is bound by the number of divergent lanes the address unit has to walk
+    // (77 % of wave cycles in vmem issue stalls), so fetch such pairs with ONE load.
 #pragma unroll kCornerUnroll<D>
-  for (int nb = 0; nb < (1 << D); ++nb) {
-    uint32_t h;
-    float w;
-    corner<D>(c, nb, h, w);
-    const float* __restrict__ row = rows + (uint64_t)slot_of(h, size, magic, pow2) * F;
-    float v[F];
-    if constexpr (F == 2) {
-      const float2 t = *reinterpret_cast<const float2*>(row);
-      v[0] = t.x, v[1] = t.y;
-    } else if constexpr (F == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(row);
-      v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int f = 0; f < F; ++f) v[f] = row[f];
+    for (int nb = 0; nb < (1 << D); nb += 2) {
+      uint32_t h0, h1;
+      float w0, w1;
+      corner<D>(c, nb, h0, w0);
+      corner<D>(c, nb + 1, h1, w1);
+      const uint32_t s0 = slot_of(h0, size, magic, pow2), s1 = slot_of(h1, size, magic, pow2);
+      float2 v0, v1;
+      if ((s0 ^ 1u) == s1) {
+        const float4 t = *reinterpret_cast<const float4*>(rows + (uint64_t)(s0 & ~1u) * 2);
+        const float2 lo = make_float2(t.x, t.y), hi = make_float2(t.z, t.w);
+        v0 = (s0 & 1u) ? hi : lo;
+        v1 = (s0 & 1u) ? lo : hi;
+      } else {
+        v0 = *reinterpret_cast<const float2*>(rows + (uint64_t)s0 * 2);
+        v1 = *reinterpret_cast<const float2*>(rows + (uint64_t)s1 * 2);
+      }
+      acc[0] = acc[0] + v0.x * w0;
+      acc[1] = acc[1] + v0.y * w0;
+      acc[0] = acc[0] + v1.x * w1;
+      acc[1] = acc[1] + v1.y * w1;
     }
+  } else {
+#pragma unroll kCornerUnroll<D>
+    for (int nb = 0; nb < (1 << D); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, nb, h, w);
+      const float* __restrict__ row = rows + (uint64_t)slot_of(h, size, magic, pow2) * F;
+      float v[F];
+      if constexpr (F == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(row);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+      } else {
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = acc[f] + v[f] * w;
+        for (int f = 0; f < F; ++f) v[f] = row[f];
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = acc[f] + v[f] * w;
+    }
   }
   float* __restrict__ o = out + (int64_t)level * sl + i * sr;
   if constexpr (F == 2) {

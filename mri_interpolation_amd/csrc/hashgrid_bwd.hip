@@ -38,6 +38,7 @@ constexpr int kAccThreads = 1024;
 constexpr int kStageWords = 12288;  // 48 KiB LDS staging buffer of the scatter kernel (2 workgroups/CU)
 constexpr int kBinThreads = 512;
 constexpr int kMaxParts = 256;        // slices per level handled by the binned path
+constexpr int kCountChunks = 8;       // the count kernel walks 8 scatter chunks per workgroup
 constexpr int kHeaderWords = 64;      // per-level max|g| bits
 constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
 
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   const bool pow2 = tab.pow2[level] != 0;
   const uint32_t slot_mask = (1u << plan.log2_slots) - 1u;
   const float* __restrict__ res = tab.res[level];
-  const int64_t i_begin = (int64_t)blockIdx.x * plan.coords_per_block;
-  const int64_t i_end = min(n, i_begin + plan.coords_per_block);
+  const int chunk = SCATTER ? plan.coords_per_block : plan.coords_per_block * kCountChunks;
+  const int64_t i_begin = (int64_t)blockIdx.x * chunk;
+  const int64_t i_end = min(n, i_begin + chunk);
 
   for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
   if (threadIdx.x == 0) wg_max = 0u;
@@ -274,41 +276,40 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4);
-  // the next group's loads are issued before the current group's LDS atomics
+  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4),
+  // kGroups such loads per array in flight before the first LDS atomic: the kernel is latency
+  // bound (78 % of wave cycles in s_waitcnt), not LDS bound
+  constexpr int kGroups = 4;
   const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
   const uint32_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
   const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
-  uint32_t k = k_lo + 4 * threadIdx.x;
-  uint4 rel = make_uint4(0, 0, 0, 0);
-  float4 val[F];
-  if (k < k_vec) {
-    rel = *reinterpret_cast<const uint4*>(slot_ptr + k);
+  for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
+    uint4 rel[kGroups];
+    float4 val[kGroups][F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) val[f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k);
-  }
-  while (k < k_vec) {
-    const uint32_t k_next = k + 4 * kAccThreads;
-    uint4 rel_n = make_uint4(0, 0, 0, 0);
-    float4 val_n[F];
-    if (k_next < k_vec) {
-      rel_n = *reinterpret_cast<const uint4*>(slot_ptr + k_next);
+    for (int g = 0; g < kGroups; ++g) {
+      const uint32_t k = k0 + g * 4 * kAccThreads;
+      if (k < k_vec) {
+        rel[g] = *reinterpret_cast<const uint4*>(slot_ptr + k);
 #pragma unroll
-      for (int f = 0; f < F; ++f)
-        val_n[f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k_next);
+        for (int f = 0; f < F; ++f)
+          val[g][f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k);
+      }
     }
-    const uint32_t r4[4] = {rel.x, rel.y, rel.z, rel.w};
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      const float v4[4] = {val[f].x, val[f].y, val[f].z, val[f].w};
+    for (int g = 0; g < kGroups; ++g) {
+      const uint32_t k = k0 + g * 4 * kAccThreads;
+      if (k < k_vec) {
+        const uint32_t r4[4] = {rel[g].x, rel[g].y, rel[g].z, rel[g].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
+        for (int f = 0; f < F; ++f) {
+          const float v4[4] = {val[g][f].x, val[g][f].y, val[g][f].z, val[g][f].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
+        }
+      }
     }
-    rel = rel_n;
-#pragma unroll
-    for (int f = 0; f < F; ++f) val[f] = val_n[f];
-    k = k_next;
   }
   for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) {
     const uint32_t rel_t = slot_ptr[kt];
@@ -446,7 +447,9 @@ struct BinnedLaunch {
                  int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
     if constexpr (D <= 4 && F <= 4) {
       const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
-      hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
+      const dim3 count_grid((unsigned)ceil_div(n, plan.coords_per_block * kCountChunks),
+                            plan.n_entries);
+      hipLaunchKernelGGL((bin_kernel<D, F, false>), count_grid, dim3(kBinThreads), 0, st, tab, plan,
                          x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
                          w.counts, plan.total_bins);
