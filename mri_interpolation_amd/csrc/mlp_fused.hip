@@ -372,6 +372,277 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// H = 128: two teams of four waves per workgroup.
+//
+// With 156 KiB of weights + activations only ONE workgroup fits a CU, so with four waves every
+// SIMD holds a single wave and nothing covers its VALU / LDS phases (epilogues, output layer,
+// dz2): measured 55 % matrix-pipe busy.  Here a 512-thread workgroup runs two teams that share
+// the resident weights; each team owns a 32-coordinate tile (its own x / h1 / h2 images) and
+// walks the same nine barrier-separated segments, but team 1 starts four segments late.  Every
+// SIMD then hosts one wave of each team in DIFFERENT segments, so one team's MFMA chains run
+// beside the other team's VALU work.  All eight waves meet at every s_barrier (same count per
+// team: 4 extra barriers before team 1's first tile, 4 after team 0's last).
+constexpr int kTeamTile = 32;
+constexpr int kTeamThreads = 256;
+
+template <int H, int KP>
+struct TeamSmem {
+  static constexpr int ldw2 = H + 1, ldw1 = KP + 1, lda = H + 1, ldx = KP + 1;
+  float w2[H * ldw2];
+  float w1[H * ldw1];
+  float w3[H], b1[H], b2[H];
+  struct Team {
+    float h1[kTeamTile * lda];
+    float h2[kTeamTile * lda];
+    float xs[kTeamTile * ldx];
+    float dy[kTeamTile];
+    float ypart[8 * kTeamTile];
+  } team[2];
+};
+
+template <int H, int KP, bool TRAIN>
+__global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const FusedArgs a) {
+  static_assert(H == 128 && KP == 32, "team kernel is laid out for 32 -> 128 -> 128 -> 1");
+  using S = TeamSmem<H, KP>;
+  __shared__ S sm;
+  const int team = threadIdx.x / kTeamThreads;
+  const int tid = threadIdx.x % kTeamThreads;        // thread within the team
+  const int lane = tid & 63, w = tid >> 6;           // wave within the team: owns block w
+  const int l31 = lane & 31, lh = lane >> 5;
+  typename S::Team& tm = sm.team[team];
+
+  {  // resident weights: W2 with 16-byte loads (all in flight before the first LDS store)
+    constexpr int kW2Vec = H * H / 4 / (2 * kTeamThreads);
+    float4 v[kW2Vec];
+#pragma unroll
+    for (int q = 0; q < kW2Vec; ++q)
+      v[q] = reinterpret_cast<const float4*>(a.w2)[threadIdx.x + q * 2 * kTeamThreads];
+#pragma unroll
+    for (int q = 0; q < kW2Vec; ++q) {
+      const int e = (threadIdx.x + q * 2 * kTeamThreads) * 4;
+      float* dst = sm.w2 + (e / H) * S::ldw2 + (e % H);
+      dst[0] = v[q].x, dst[1] = v[q].y, dst[2] = v[q].z, dst[3] = v[q].w;
+    }
+  }
+  for (int e = threadIdx.x; e < H * KP; e += 2 * kTeamThreads) {
+    const int o = e / KP, k = e % KP;
+    sm.w1[o * S::ldw1 + k] = k < a.k_in ? a.w1[o * a.k_in + k] : 0.f;
+  }
+  for (int e = threadIdx.x; e < H; e += 2 * kTeamThreads) {
+    sm.w3[e] = a.w3[e];
+    sm.b1[e] = a.b1[e];
+    sm.b2[e] = a.b2[e];
+  }
+  const float b3 = a.b3[0];
+
+  f32x16 g_w2[1][4];
+  f32x16 g_w1[1][1];
+  zero(g_w2);
+  zero(g_w1);
+  float g_b1 = 0.f, g_b2 = 0.f, g_w3 = 0.f, g_b3 = 0.f, loss = 0.f;
+
+  // x tile of a team: 32 features x 32 coordinates = 256 float4 pieces, one per thread
+  auto load_x = [&](int64_t m0) {
+    const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < a.k_in && m0 + c4 < a.n) {
+      const float* src = a.x + (int64_t)k * a.n + m0 + c4;
+      if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (m0 + c4 + 1 < a.n) v.y = src[1];
+        if (m0 + c4 + 2 < a.n) v.z = src[2];
+        if (m0 + c4 + 3 < a.n) v.w = src[3];
+      }
+    }
+    return v;
+  };
+
+  const int64_t tiles = (a.n + kTeamTile - 1) / kTeamTile;
+  const int64_t rounds = (tiles + 2 * (int64_t)gridDim.x - 1) / (2 * (int64_t)gridDim.x);
+  auto tile_of = [&](int64_t r) { return (r * gridDim.x + blockIdx.x) * 2 + team; };
+  float4 x_next = load_x(tile_of(0) * kTeamTile);  // beyond n -> zeros
+
+  __syncthreads();  // weights resident
+  if (TRAIN && team == 1) {  // stagger: team 1 runs four segments behind team 0
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+  }
+  for (int64_t r = 0; r < rounds; ++r) {
+    // a team without a tile in the last round still walks the segments (rows >= n are inert)
+    const int64_t m0 = tile_of(r) * kTeamTile;
+    __syncthreads();  // S0
+    {
+      const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
+      float* dst = tm.xs + c4 * S::ldx + k;
+      dst[0] = x_next.x, dst[S::ldx] = x_next.y, dst[2 * S::ldx] = x_next.z,
+      dst[3 * S::ldx] = x_next.w;
+    }
+    if (r + 1 < rounds) x_next = load_x(tile_of(r + 1) * kTeamTile);
+    __syncthreads();  // S1: layer 1
+    {
+      f32x16 acc[1][1];
+      zero(acc);
+      mfma32<1, 1>(acc, tm.xs + l31 * S::ldx + lh, 0, 2, sm.w1 + (w * 32 + l31) * S::ldw1 + lh,
+                   0, 2, KP / 2);
+      const int col = w * 32 + l31;
+      const float bias = sm.b1[col];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        tm.h1[acc_row(q, lh) * S::lda + col] = fmaxf(acc[0][0][q] + bias, 0.f);
+    }
+    __syncthreads();  // S2: layer 2
+    {
+      f32x16 acc[1][1];
+      zero(acc);
+      mfma32<1, 1>(acc, tm.h1 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) * S::ldw2 + lh,
+                   0, 2, H / 2);
+      const int col = w * 32 + l31;
+      const float bias = sm.b2[col];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        tm.h2[acc_row(q, lh) * S::lda + col] = fmaxf(acc[0][0][q] + bias, 0.f);
+    }
+    __syncthreads();  // S3: output layer, thread = (coordinate l31, eighth of H)
+    {
+      constexpr int Q = H / 8;
+      const int part = w * 2 + lh;
+      const float* row = tm.h2 + l31 * S::lda + part * Q;
+      const float* wv = sm.w3 + part * Q;
+      float sacc = 0.f;
+#pragma unroll
+      for (int o = 0; o < Q; ++o) sacc += row[o] * wv[o];
+      tm.ypart[part * kTeamTile + l31] = sacc;
+    }
+    __syncthreads();  // S4: prediction, loss, dy
+    if (tid < kTeamTile) {
+      const int64_t m = m0 + tid;
+      float y = b3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y += tm.ypart[q * kTeamTile + tid];
+      float d = 0.f;
+      if (m < a.n) {
+        if (a.y) a.y[m] = y;
+        if (TRAIN) {
+          const float diff = y - a.target[m];
+          loss += diff * diff;
+          d = diff * a.grad_scale;
+          g_b3 += d;
+        }
+      }
+      tm.dy[tid] = d;
+    }
+    if (!TRAIN) continue;
+    __syncthreads();  // S5: dz2 in place, dW3 / db2 partials
+    {
+      const int o = tid % H, c0 = (tid / H) * (kTeamTile / 2);
+      const float w3o = sm.w3[o];
+#pragma unroll 8
+      for (int c = c0; c < c0 + kTeamTile / 2; ++c) {
+        const float h = tm.h2[c * S::lda + o];
+        const float d = tm.dy[c];
+        g_w3 += d * h;
+        const float dz = h > 0.f ? d * w3o : 0.f;
+        g_b2 += dz;
+        tm.h2[c * S::lda + o] = dz;
+      }
+    }
+    __syncthreads();  // S6: dW2 += dz2^T h1 ; dz1 = dz2 W2 (accumulators only)
+    mfma32<1, 4>(g_w2, tm.h2 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                 tm.h1 + l31 + lh * S::lda, 32, 2 * S::lda, kTeamTile / 2);
+    f32x16 dz1[1][1];
+    zero(dz1);
+    mfma32<1, 1>(dz1, tm.h2 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) + lh * S::ldw2, 0,
+                 2 * S::ldw2, H / 2);
+    __syncthreads();  // S7: dz1 = (.) * (h1 > 0) over h1
+    {
+      const int col = w * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float* p = tm.h1 + acc_row(q, lh) * S::lda + col;
+        const float v = *p > 0.f ? dz1[0][0][q] : 0.f;
+        g_b1 += v;
+        *p = v;
+      }
+    }
+    __syncthreads();  // S8: dW1 += dz1^T x ; dx^T = W1^T dz1^T
+    mfma32<1, 1>(g_w1, tm.h1 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                 tm.xs + l31 + lh * S::ldx, 0, 2 * S::ldx, kTeamTile / 2);
+    if (a.dx) {
+      const int l15 = lane & 15, lq = lane >> 4;
+      const int kb = w >> 1, cb = w & 1;  // 2 x 2 tiles of 16 x 16: features x coordinates
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* pa = sm.w1 + lq * S::ldw1 + kb * 16 + l15;
+      const float* pb = tm.h1 + (cb * 16 + l15) * S::lda + lq;
+#pragma unroll 8
+      for (int st = 0; st < H / 4; ++st)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[st * 4 * S::ldw1], pb[st * 4], acc, 0, 0, 0);
+      const int64_t m = m0 + cb * 16 + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = kb * 16 + lq * 4 + q;
+        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = acc[q];
+      }
+    }
+  }
+  if (!TRAIN) return;
+  if (team == 0) {
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+  }
+  __syncthreads();  // both teams are done with their activation images
+
+  // ---- one slab per team ------------------------------------------------------------------
+  float* slab = a.partial + ((int64_t)blockIdx.x * 2 + team) * slab_floats(H, a.k_in);
+  float* p_w1 = slab;
+  float* p_b1 = p_w1 + H * a.k_in;
+  float* p_w2 = p_b1 + H;
+  float* p_b2 = p_w2 + H * H;
+  float* p_w3 = p_b2 + H;
+  float* p_b3 = p_w3 + H;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      p_w2[(w * 32 + acc_row(q, lh)) * H + tj * 32 + l31] = g_w2[0][tj][q];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    if (l31 < a.k_in) p_w1[(w * 32 + acc_row(q, lh)) * a.k_in + l31] = g_w1[0][0][q];
+  float* red = tm.h2;  // scratch (team private)
+  red[tid] = g_b1;
+  __syncthreads();
+  if (tid < H) p_b1[tid] = red[(tid / 32) * 64 + (tid & 31)] + red[(tid / 32) * 64 + 32 + (tid & 31)];
+  __syncthreads();
+  red[tid] = g_b2;
+  red[kTeamThreads + tid] = g_w3;
+  __syncthreads();
+  if (tid < H) {
+    p_b2[tid] = red[tid] + red[H + tid];
+    p_w3[tid] = red[kTeamThreads + tid] + red[kTeamThreads + H + tid];
+  }
+  __syncthreads();
+  if (tid < kTeamTile) {
+    red[tid] = g_b3;
+    red[kTeamTile + tid] = loss;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sb = 0.f, sl = 0.f;
+    for (int c = 0; c < kTeamTile; ++c) {
+      sb += red[c];
+      sl += red[kTeamTile + c];
+    }
+    p_b3[0] = sb;
+    p_b3[1] = sl * a.inv_n;
+  }
+}
+
 // Sum the per-workgroup slabs in a fixed order into the gradient tensors (accumulating).
 struct ReduceArgs {
   const float* partial;
@@ -423,10 +694,12 @@ int launch(const FusedArgs& a, bool train, int blocks, hipStream_t st) {
 }
 
 int pick_blocks(int hidden, int64_t n) {
-  const int per_cu = hidden == 128 ? 1 : 2;  // LDS footprint: 156 KiB vs 52-75 KiB
-  const int64_t tiles = ceil_div(n, kTile);
-  return (int)std::min<int64_t>(tiles, 256 * per_cu);
+  if (hidden == 128)  // team kernel: one 512-thread workgroup per CU, two 32-row tiles per round
+    return (int)std::min<int64_t>(ceil_div(n, 2 * kTeamTile), 256);
+  return (int)std::min<int64_t>(ceil_div(n, kTile), 512);  // 52-75 KiB of LDS: two per CU
 }
+
+int slab_count(int hidden, int blocks) { return hidden == 128 ? 2 * blocks : blocks; }
 
 bool supported(int k_in, int hidden, int dim_out) {
   if (dim_out != 1 || k_in < 1) return false;
@@ -436,7 +709,15 @@ bool supported(int k_in, int hidden, int dim_out) {
 }
 
 int dispatch(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
-  if (hidden == 128) return launch<128, 32>(a, train, blocks, st);
+  if (hidden == 128) {
+    if (train)
+      hipLaunchKernelGGL((tiny_mlp_team_kernel<128, 32, true>), dim3(blocks),
+                         dim3(2 * kTeamThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((tiny_mlp_team_kernel<128, 32, false>), dim3(blocks),
+                         dim3(2 * kTeamThreads), 0, st, a);
+    return check_launch("tiny_mlp_team_kernel");
+  }
   if (a.k_in <= 32) return launch<64, 32>(a, train, blocks, st);
   return launch<64, 64>(a, train, blocks, st);
 }
@@ -452,7 +733,8 @@ extern "C" int mri_tiny_mlp_supported(int32_t k_in, int32_t hidden, int32_t dim_
 
 extern "C" int64_t mri_tiny_mlp_workspace_bytes(int32_t k_in, int32_t hidden, int64_t n) {
   if (!supported(k_in, hidden, 1)) return -1;
-  return (int64_t)pick_blocks(hidden, std::max<int64_t>(n, 1)) * slab_floats(hidden, k_in) * 4;
+  return (int64_t)slab_count(hidden, pick_blocks(hidden, std::max<int64_t>(n, 1))) *
+         slab_floats(hidden, k_in) * 4;
 }
 
 extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int32_t hidden,
@@ -485,9 +767,10 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
   MRI_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && loss_out, "NULL gradient pointer");
   const int blocks = pick_blocks(hidden, n);
   const int slab = slab_floats(hidden, k_in);
-  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)blocks * slab * 4,
+  const int slabs = slab_count(hidden, blocks);
+  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)slabs * slab * 4,
               "tiny MLP needs a workspace of %lld bytes (mri_tiny_mlp_workspace_bytes)",
-              (long long)blocks * slab * 4);
+              (long long)slabs * slab * 4);
   FusedArgs a{};
   a.x = x, a.target = target;
   a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3;
@@ -497,7 +780,7 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
   a.inv_n = (float)(1.0 / (double)n);
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
-  r.partial = a.partial, r.slabs = blocks, r.slab = slab, r.n_seg = 7;
+  r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7;
   const int lens[7] = {hidden * k_in, hidden, hidden * hidden, hidden, hidden, 1, 1};
   float* dsts[7] = {d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, loss_out};
   int off = 0;

@@ -68,6 +68,26 @@ def gemm_bench():
               f"bwd_weight {t_w:.3f} ms ({fl / t_w:.1f} TF)", flush=True)
 
 
+
+
+def mlp_bench():
+    """Fixed vs per-coordinate cost of the fused tiny-MLP kernel."""
+    for hidden, k_in in [(128, 32), (64, 32)]:
+        params = [(torch.randn(hidden, k_in, device="cuda") * 0.1, torch.zeros(hidden, device="cuda")),
+                  (torch.randn(hidden, hidden, device="cuda") * 0.1, torch.zeros(hidden, device="cuda")),
+                  (torch.randn(1, hidden, device="cuda") * 0.1, torch.zeros(1, device="cuda"))]
+        grads = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in params]
+        loss = torch.zeros(1, device="cuda")
+        for logn in (14, 16, 17, 18, 19, 20):
+            n = 1 << logn
+            x = torch.randn(k_in, n, device="cuda")
+            t = torch.rand(n, 1, device="cuda")
+            dx = torch.empty_like(x)
+            ms = timeit(lambda: ops.tiny_mlp_train(x, t, params, grads, loss, d_x=dx), iters=20)
+            fl = 6.0 * (k_in * hidden + hidden * hidden + hidden) * n
+            print(f"H={hidden} n=2^{logn}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TF", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "hash"
-    {"hash": hash_bench, "gemm": gemm_bench}[what]()
+    {"hash": hash_bench, "gemm": gemm_bench, "mlp": mlp_bench}[what]()
