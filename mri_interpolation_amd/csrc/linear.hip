@@ -23,6 +23,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -79,56 +80,51 @@ struct TileRegs {
   float v[kPer];
 };
 
+// hipcc wraps every conditionally executed load in its own branch and waits for it before the
+// join, which serialises the loads of a tile (one HBM latency each).  So: tiles that lie fully
+// inside the operand (almost all of them) take a path with NO per-element conditions, and edge
+// tiles read clamped, always-valid addresses and zero the out-of-range values afterwards.
 template <int O>
 __device__ __forceinline__ void load_tile(TileRegs<O>& r, const Operand& op, int64_t o0,
                                           int64_t o_end, int64_t c0, int64_t c_end) {
   const int t = threadIdx.x;
   constexpr int kPer = TileRegs<O>::kPer;
-  if (op.mode == 1) {  // float4 along the contraction
+  const bool interior = o0 + O <= o_end && c0 + KB <= c_end;  // workgroup-uniform
+  if (interior && op.mode == 1) {  // float4 along the contraction
 #pragma unroll
     for (int q = 0; q < kPer / 4; ++q) {
       const int v = t + q * kThreads;
       const int o = v / (KB / 4), c4 = (v % (KB / 4)) * 4;
-      const int64_t go = o0 + o, gc = c0 + c4;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (go < o_end) {
-        const float* src = op.ptr + go * op.os + gc;
-        if (gc + 3 < c_end) {
-          x = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (gc + 0 < c_end) x.x = src[0];
-          if (gc + 1 < c_end) x.y = src[1];
-          if (gc + 2 < c_end) x.z = src[2];
-        }
-      }
+      const float4 x = *reinterpret_cast<const float4*>(op.ptr + (o0 + o) * op.os + c0 + c4);
       r.v[4 * q] = x.x, r.v[4 * q + 1] = x.y, r.v[4 * q + 2] = x.z, r.v[4 * q + 3] = x.w;
     }
-  } else if (op.mode == 2) {  // float4 along the outer index
+  } else if (interior && op.mode == 2) {  // float4 along the outer index
 #pragma unroll
     for (int q = 0; q < kPer / 4; ++q) {
       const int v = t + q * kThreads;
       const int c = v / (O / 4), o4 = (v % (O / 4)) * 4;
-      const int64_t go = o0 + o4, gc = c0 + c;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gc < c_end) {
-        const float* src = op.ptr + gc * op.cs + go;
-        if (go + 3 < o_end) {
-          x = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (go + 0 < o_end) x.x = src[0];
-          if (go + 1 < o_end) x.y = src[1];
-          if (go + 2 < o_end) x.z = src[2];
-        }
-      }
+      const float4 x = *reinterpret_cast<const float4*>(op.ptr + (c0 + c) * op.cs + o0 + o4);
       r.v[4 * q] = x.x, r.v[4 * q + 1] = x.y, r.v[4 * q + 2] = x.z, r.v[4 * q + 3] = x.w;
     }
   } else {
+    // element (o, c) of the tile for register slot q, in the order store_tile expects
+    const int64_t o_last = o_end - 1, c_last = c_end - 1;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
-      const int v = t + q * kThreads;
-      const int o = v / KB, c = v % KB;
+      int o, c;
+      if (op.mode == 1) {
+        const int v = t + (q / 4) * kThreads;
+        o = v / (KB / 4), c = (v % (KB / 4)) * 4 + (q & 3);
+      } else if (op.mode == 2) {
+        const int v = t + (q / 4) * kThreads;
+        c = v / (O / 4), o = (v % (O / 4)) * 4 + (q & 3);
+      } else {
+        const int v = t + q * kThreads;
+        o = v / KB, c = v % KB;
+      }
       const int64_t go = o0 + o, gc = c0 + c;
-      r.v[q] = (go < o_end && gc < c_end) ? op.ptr[go * op.os + gc * op.cs] : 0.f;
+      const float x = op.ptr[min(go, o_last) * op.os + min(gc, c_last) * op.cs];
+      r.v[q] = (go <= o_last && gc <= c_last) ? x : 0.f;
     }
   }
 }
@@ -260,56 +256,74 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 f32 MFMA: col = lane & 31,
-  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // Tiles that lie fully inside the output (workgroup-uniform test) run without per-element
+  // bounds checks, so the loads of the derivative matrix are issued back to back.
+  auto emit = [&](auto checked_tag) {
+    constexpr bool kChecked = decltype(checked_tag)::value;
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) {
+    for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) {
-      const int64_t j = j0 + (wj * TJ + tj) * 32 + l31;
-      if (j >= a.J) continue;
-      float bj = 0.f;
-      if (EPI == EPI_FORWARD && a.bias) bj = a.bias[j];
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int64_t j = j0 + (wj * TJ + tj) * 32 + l31;
+        if (kChecked && j >= a.J) continue;
+        float bj = 0.f;
+        if (EPI == EPI_FORWARD && a.bias) bj = a.bias[j];
+        const int64_t i_first = i0 + (wi * TI + ti) * 32 + 4 * lh;
+        float g[16];
+        if (EPI == EPI_BACKWARD_DATA && a.deriv_mode != MRI_DERIV_NONE) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t i = i0 + (wi * TI + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (i >= a.I) continue;
-        float v = acc[ti][tj][r];
-        if (EPI == EPI_FORWARD) {
-          v += bj;
-          float d = 1.0f;
-          switch (a.act) {
-            case MRI_ACT_RELU:
-              v = fmaxf(v, 0.f);
-              break;
-            case MRI_ACT_SINE: {
-              const float u = a.w0 * v;
-              float s, c;
-              sincosf(u, &s, &c);
-              v = s;
-              d = a.w0 * c;
-            } break;
-            case MRI_ACT_GELU:
-              d = gelu_grad_f(v);
-              v = gelu_f(v);
-              break;
-            default:
-              break;
+          for (int r = 0; r < 16; ++r) {
+            const int64_t i = i_first + (r & 3) + 8 * (r >> 2);
+            g[r] = a.deriv_in[(kChecked ? min(i, a.I - 1) : i) * a.ldd_in + j];
           }
-          a.out[i * a.ldo + j] = v;
-          if (a.deriv_out) a.deriv_out[i * a.ldd_out + j] = d;
-        } else if (EPI == EPI_BACKWARD_DATA) {
-          if (a.deriv_mode == MRI_DERIV_MUL) {
-            v *= a.deriv_in[i * a.ldd_in + j];
-          } else if (a.deriv_mode == MRI_DERIV_RELU_MASK) {
-            v = a.deriv_in[i * a.ldd_in + j] > 0.f ? v : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t i = i_first + (r & 3) + 8 * (r >> 2);
+          if (kChecked && i >= a.I) continue;
+          float v = acc[ti][tj][r];
+          if (EPI == EPI_FORWARD) {
+            v += bj;
+            float d = 1.0f;
+            switch (a.act) {
+              case MRI_ACT_RELU:
+                v = fmaxf(v, 0.f);
+                break;
+              case MRI_ACT_SINE: {
+                const float u = a.w0 * v;
+                float sn, cs;
+                sincosf(u, &sn, &cs);
+                v = sn;
+                d = a.w0 * cs;
+              } break;
+              case MRI_ACT_GELU:
+                d = gelu_grad_f(v);
+                v = gelu_f(v);
+                break;
+              default:
+                break;
+            }
+            a.out[i * a.ldo + j] = v;
+            if (a.deriv_out) a.deriv_out[i * a.ldd_out + j] = d;
+          } else if (EPI == EPI_BACKWARD_DATA) {
+            if (a.deriv_mode == MRI_DERIV_MUL) {
+              v *= g[r];
+            } else if (a.deriv_mode == MRI_DERIV_RELU_MASK) {
+              v = g[r] > 0.f ? v : 0.f;
+            }
+            a.out[i * a.ldo + j] = v;
+          } else {
+            atomicAdd(a.out + i * a.ldo + j, v);
           }
-          a.out[i * a.ldo + j] = v;
-        } else {
-          atomicAdd(a.out + i * a.ldo + j, v);
         }
       }
     }
-  }
+  };
+  if (i0 + BI <= a.I && j0 + BJ <= a.J)
+    emit(std::false_type{});
+  else
+    emit(std::true_type{});
   if (want_rowsum && threadIdx.x < BI && i0 + threadIdx.x < a.I)
     atomicAdd(a.rowsum_out + i0 + threadIdx.x, rowsum);
 }
