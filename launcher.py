@@ -41,6 +41,9 @@ def parse_args(argv=None):
     p.add_argument("--n_layers", type=int)
     p.add_argument("--tiny_mlp", action="store_true",
                    help="HashMLP with the fused ReLU tiny-MLP decoder of hash_config.json")
+    p.add_argument("--holdout_odd_frames", action="store_true",
+                   help="train on the even frames of the last axis, report PSNR on the odd ones "
+                        "(BASELINE config 5 protocol)")
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--max_steps", type=int, default=-1)
     p.add_argument("--log_every", type=int, default=50)
@@ -89,7 +92,7 @@ def main(argv=None):
         config.enco_config = cfg.load_json(enco_path)  # reference launcher.py:73-74
     overrides = {k: v for k, v in vars(args).items()
                  if k not in ("synthetic", "tiny_mlp", "out_dir", "max_steps", "log_every",
-                              "enco_config_path")}
+                              "enco_config_path", "holdout_odd_frames")}
     cfg.apply_overrides(config, overrides)
 
     # ---- data ---------------------------------------------------------------------------
@@ -123,6 +126,12 @@ def main(argv=None):
     datamodule.setup()
     train_loader = datamodule.train_dataloader(rank, world)
     test_loader = datamodule.test_dataloader()
+    if args.holdout_odd_frames:  # train on even frames, coordinates from the full time grid
+        even = datamodules.MriImage(volume=volume, norm_siren=config.norm_siren,
+                                    frames=slice(0, None, 2))
+        lo, hi = parallel.voxel_range(even.shape, rank, world)
+        train_loader = datamodules.DeviceLoader(even, config.batch_size, shuffle=True, lo=lo,
+                                                hi=hi, seed=config.seed + rank)
 
     # ---- training -------------------------------------------------------------------------
     trainer = Trainer(max_epochs=config.epochs, max_steps=args.max_steps, precision=32,
@@ -161,6 +170,14 @@ def main(argv=None):
         interp_im = np.array(interp.reshape(shape).detach().cpu().numpy(), dtype=np.float32)
         nifti.save(interp_im, os.path.join(out_dir, f"interpolation{tuple(shape)}.nii.gz"))
 
+    if args.holdout_odd_frames:
+        odd = datamodules.MriImage(volume=volume, norm_siren=config.norm_siren,
+                                   frames=slice(1, None, 2))
+        held = torch.concat(trainer.predict(
+            model, datamodules.DeviceLoader(odd, config.batch_size, shuffle=False)))
+        config.psnr_heldout_db = (psnr((held + 1) / 2, (odd.pixels + 1) / 2)
+                                  if config.norm_siren else psnr(held, odd.pixels))
+        print(f"PSNR on the {odd.shape[-1]} held-out odd frames: {config.psnr_heldout_db:.2f} dB")
     config.train_seconds = train_seconds
     config.psnr_db = quality
     config.coords_per_second = trainer.throughput[-1] if trainer.throughput else None

@@ -53,24 +53,33 @@ class MriImage:
     """Dataset for implicit-representation training: coordinates in x, intensity in y."""
 
     def __init__(self, config=None, image_path: Optional[str] = None, norm_siren: bool = False,
-                 volume=None, device=None, *args, **kwargs):
+                 volume=None, device=None, frames: Optional[slice] = None, *args, **kwargs):
+        """`frames` keeps a subset of the LAST axis (e.g. slice(0, None, 2) = even time frames)
+        while coordinates still come from the FULL grid -- the held-out-frame protocol of
+        reference interp.py:35 / legacy_code/hash_experimentation.py:284,313-317.  Intensities
+        are normalised with the min / max of the full volume."""
         if volume is None:
             path = image_path if image_path else config.image_path
             volume = nifti.load(path)
         self.device = torch.device(device if device is not None else "cuda")
         vol = torch.as_tensor(volume, dtype=torch.float32).to(self.device)
-        self.shape = tuple(int(s) for s in vol.shape)
-        self.dim_in = len(self.shape)
+        full_shape = tuple(int(s) for s in vol.shape)
         self.norm_siren = norm_siren
         lo = -1.0 if norm_siren else 0.0
         # axes built with torch.linspace on the CPU, as the reference does, then uploaded
-        axes = [torch.linspace(lo, 1.0, s) for s in self.shape]
+        axes = [torch.linspace(lo, 1.0, s) for s in full_shape]
+        v_min, v_max = torch.min(vol), torch.max(vol)
+        if frames is not None:
+            axes[-1] = axes[-1][frames]
+            vol = vol[..., frames].contiguous()
+        self.shape = tuple(int(s) for s in vol.shape)
+        self.dim_in = len(self.shape)
         self.axis_offset = [0]
         for a in axes[:-1]:
             self.axis_offset.append(self.axis_offset[-1] + a.numel())
         self.axes = torch.cat(axes).to(self.device)
         pix = vol.flatten()
-        pix = (pix - torch.min(pix)) / (torch.max(pix) - torch.min(pix))
+        pix = (pix - v_min) / (v_max - v_min)
         if norm_siren:
             pix = pix * 2 - 1
         self.pixels = pix.unsqueeze(-1).contiguous()  # (N, 1), C-order flatten
