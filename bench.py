@@ -64,6 +64,18 @@ def phase_model(w, step, n_params):
     return out
 
 
+def pmc_traffic(workload, phase):
+    """HBM bytes per launch of the phase's kernels from the committed rocprofv3 PMC summary
+    (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections applied as the summary
+    states) -- measured offline by tools/summarize_prof.py, None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    return table.get(workload, {}).get(phase)
+
+
 def cpu_baseline(w, name):
     """The oracle (CPU restatement of the reference's step) timed on the host cores, on a
     bounded sample of the same workload."""
@@ -168,6 +180,9 @@ def main():
             psnr = dict(steps=counter[0], db=trainer.psnr(torch.cat(preds), ds.pixels)
                         if not w["norm_siren"] else
                         trainer.psnr((torch.cat(preds) + 1) / 2, (ds.pixels + 1) / 2))
+    if world > 1:  # leave the process group together (rank 0 was busy with the PSNR pass)
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 
@@ -182,8 +197,8 @@ def main():
     else:
         roof = dict(bound="mfma", achieved=amount / sec / 1e12, peak=MFMA_F32_PEAK_TF,
                     unit="TFLOP/s")
-    roof.update(frac=roof["achieved"] / roof["peak"], traffic=None, kernel=dominant,
-                ms_per_launch=phases[dominant])
+    roof.update(frac=roof["achieved"] / roof["peak"], traffic=pmc_traffic(args.workload, dominant),
+                kernel=dominant, ms_per_launch=phases[dominant])
     result = {
         "metric": "coord-samples/sec (train)", "value": value, "unit": "coord-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
