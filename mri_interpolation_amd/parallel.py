@@ -17,17 +17,19 @@ import torch.distributed as dist
 
 
 def env_world() -> Tuple[int, int, int]:
-    """(rank, world_size, local_rank) from the torchrun environment (1 process = 1 GPU)."""
-    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
-            int(os.environ.get("LOCAL_RANK", "0")))
+    """(rank, world_size, local_rank) from the torchrun environment (1 process = 1 GPU).
+    MRI_SINGLE_DEVICE=1 maps every rank to device 0 (multi-rank rehearsal on a one-GPU box)."""
+    local = 0 if os.environ.get("MRI_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), local
 
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the process group described by the environment; no-op for a single process."""
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if backend is None:  # "nccl" is RCCL on ROCm; MRI_DIST_BACKEND=gloo rehearses on one GPU
+            backend = os.environ.get("MRI_DIST_BACKEND",
+                                     "nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
