@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libmri_inr.so")
-SOURCES = ["hashgrid.hip", "hashgrid_bwd.hip", "linear.hip", "mlp_fused.hip", "train_ops.hip"]
+SOURCES = ["hashgrid.hip", "hashgrid_bwd.hip", "linear.hip", "linear_small.hip", "mlp_fused.hip", "train_ops.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          # the reference multiplies and adds separately (encoding.py:111-128, torch Adam);
          # keep those roundings instead of contracting to fma
@@ -43,7 +43,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libmri_inr.so; returns its path."""
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "hashgrid_common.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "hashgrid_common.h"), os.path.join(CSRC, "device_math.h"),
                os.path.join(ROOT, "include", "mri_inr.h")]
     objs, procs = [], []
     for src in SOURCES:

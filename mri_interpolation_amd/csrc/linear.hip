@@ -26,8 +26,19 @@
 #include <type_traits>
 
 #include "common.h"
+#include "device_math.h"
 
 namespace mri {
+
+// VALU kernels for layers with a tiny input (K <= 8) or output (N <= 4) width (linear_small.hip);
+// they return false when the shape is not theirs.
+bool small_forward(const float* x, int64_t xrs, int64_t xcs, const float* w, const float* b,
+                   int64_t m, int n, int k, int act, float w0, float* y, int64_t ldy, float* deriv,
+                   int64_t ldd, hipStream_t st);
+bool small_backward_data(const float* dy, int64_t lddy, const float* w, int64_t m, int n, int k,
+                         int mode, const float* g, int64_t ldg, float* dx, int64_t lddx,
+                         hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -159,15 +170,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const TileRe
   }
 }
 
-__device__ __forceinline__ float gelu_f(float z) {
-  return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float gelu_grad_f(float z) {
-  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
-  return cdf + z * pdf;
-}
-
 template <int WI, int WJ, int TI, int TJ, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
               case MRI_ACT_SINE: {
                 const float u = a.w0 * v;
                 float sn, cs;
-                sincosf(u, &sn, &cs);
+                sincos_fast(u, &sn, &cs);
                 v = sn;
                 d = a.w0 * cs;
               } break;
@@ -396,6 +398,9 @@ extern "C" int mri_linear_forward(const float* x, int64_t x_row_stride, int64_t 
   if (m == 0) return MRI_OK;
   MRI_REQUIRE(x && weight && y, "NULL device pointer");
   MRI_REQUIRE(ldy >= n && (!deriv || ldd >= n), "leading dimension smaller than n");
+  if (small_forward(x, x_row_stride, x_col_stride, weight, bias, m, n, k, activation, w0, y, ldy,
+                    deriv, ldd, (hipStream_t)stream))
+    return check_launch("small forward kernel");
   GemmArgs a{};
   a.p = make_operand(x, x_row_stride, x_col_stride);
   a.q = make_operand(weight, k, 1);
@@ -418,6 +423,10 @@ extern "C" int mri_linear_backward_data(const float* dy, int64_t lddy, const flo
   MRI_REQUIRE(dy && weight && dx, "NULL device pointer");
   MRI_REQUIRE(deriv_mode == MRI_DERIV_NONE || deriv, "deriv_mode %d needs a deriv matrix",
               deriv_mode);
+  if (dx_col_stride == 1 &&
+      small_backward_data(dy, lddy, weight, m, n, k, deriv_mode, deriv, ldd, dx, dx_row_stride,
+                          (hipStream_t)stream))
+    return check_launch("small backward-data kernel");
   GemmArgs a{};
   a.C = n, a.c_per_split = n;
   if (dx_col_stride == 1) {

@@ -177,10 +177,11 @@ def test_linear_forward_backward(amd, m, n, k, act):
     # feature-major input / output variants used by the fused trainer
     y_fm = ops.linear_forward(xg.detach().t().contiguous(), wg.detach(), bg.detach(), code, w0,
                               x_feature_major=True)
-    assert torch.equal(y_fm, yg.detach())
+    # (tiny widths run on different kernels for the two layouts: same values, other rounding)
+    assert_close(y_fm.cpu().numpy(), yg.detach().cpu().numpy(), 1e-6, "feature-major y")
     dxt = ops.linear_backward_data(dy.cuda(), wg.detach(), dx_feature_major=True)
     dx = ops.linear_backward_data(dy.cuda(), wg.detach())
-    assert torch.equal(dxt.t().contiguous(), dx)
+    assert_close(dxt.t().contiguous().cpu().numpy(), dx.cpu().numpy(), 1e-6, "feature-major dx")
 
 
 # ------------------------------------------------------------------------------ whole models
