@@ -100,6 +100,14 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  *   and always be passed with the same workspace_bytes.  May be NULL for method 1.
  */
 int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n);
+/* Optional split: the first stage of the binned backward (counting the records per table
+ * slice) needs only the coordinates, so a trainer can run it on a side stream beside the
+ * forward pass and then call mri_hashgrid_backward with `method | MRI_BWD_PREPARED` on the same
+ * workspace (same grid, n and method; nothing else may use the workspace in between). */
+#define MRI_BWD_PREPARED 16
+int mri_hashgrid_backward_prepare(const mri_grid_desc* grid, const float* x, int64_t n,
+                                  int32_t method, void* workspace, int64_t workspace_bytes,
+                                  void* stream);
 int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x, const float* d_out,
                           int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
                           int64_t dout_feat_stride, float* d_table, int32_t method,

@@ -11,6 +11,7 @@ MAX_DIM = 7
 
 ACT_IDENTITY, ACT_RELU, ACT_SINE, ACT_GELU = 0, 1, 2, 3
 DERIV_NONE, DERIV_MUL, DERIV_RELU_MASK = 0, 1, 2
+BWD_PREPARED = 16
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmri_inr.so")
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     "mri_hashgrid_forward": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _I64, _P],
     "mri_hashgrid_backward": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32, _P,
                               _I64, _P],
+    "mri_hashgrid_backward_prepare": [C.POINTER(GridDesc), _P, _I64, _I32, _P, _I64, _P],
     "mri_linear_forward": [_P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _P, _I64, _P,
                            _I64, _P],
     "mri_linear_backward_data": [_P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _I64, _I64,

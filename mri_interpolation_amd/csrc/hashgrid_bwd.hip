@@ -443,16 +443,22 @@ Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t recor
 template <int D, int F>
 struct BinnedLaunch {
   static int run(const LevelTab& tab, const BinPlan& plan, const Workspace& w, int n_levels,
-                 int acc_blocks, bool any_split, const float* x, const float* d_out, int64_t n,
-                 int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
+                 int acc_blocks, bool any_split, int phase, const float* x, const float* d_out,
+                 int64_t n, int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
+    // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
+    // forward pass); 2: the rest, after a phase-1 call on the same workspace
     if constexpr (D <= 4 && F <= 4) {
       const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
       const dim3 count_grid((unsigned)ceil_div(n, plan.coords_per_block * kCountChunks),
                             plan.n_entries);
-      hipLaunchKernelGGL((bin_kernel<D, F, false>), count_grid, dim3(kBinThreads), 0, st, tab, plan,
-                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
-      hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
-                         w.counts, plan.total_bins);
+      if (phase != 2) {
+        hipLaunchKernelGGL((bin_kernel<D, F, false>), count_grid, dim3(kBinThreads), 0, st, tab,
+                           plan, x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val,
+                           w.records, w.max_bits);
+        hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
+                           w.counts, plan.total_bins);
+      }
+      if (phase == 1) return check_launch("hashgrid backward (count)");
       hipLaunchKernelGGL((bin_kernel<D, F, true>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
                          x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
@@ -485,16 +491,15 @@ extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* gr
   return workspace_bytes(words, records, grid->n_features);
 }
 
-extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
-                                     const float* d_out, int64_t n, int64_t dout_level_stride,
-                                     int64_t dout_row_stride, int64_t dout_feat_stride,
-                                     float* d_table, int32_t method, void* workspace,
-                                     int64_t workspace_bytes_given, void* stream) {
+namespace {
+int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
+                  int64_t sl, int64_t sr, int64_t sf, float* d_table, int32_t method, int phase,
+                  void* workspace, int64_t workspace_bytes_given, void* stream) {
   if (int rc = validate(grid)) return rc;
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
   if (n == 0) return MRI_OK;
-  MRI_REQUIRE(x && d_out && d_table, "NULL device pointer");
+  MRI_REQUIRE(x && (phase == 1 || (d_out && d_table)), "NULL device pointer");
   const int F = grid->n_features;
   BinPlan plan;
   uint32_t atomic_mask;
@@ -512,13 +517,31 @@ extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
     const Workspace w = carve(workspace, workspace_bytes_given, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, w, grid->n_levels, acc_blocks,
-                                    ws_words > 0, x, d_out, n, dout_level_stride, dout_row_stride,
-                                    dout_feat_stride, d_table, (hipStream_t)stream);
+                                    ws_words > 0, phase, x, d_out, n, sl, sr, sf, d_table,
+                                    (hipStream_t)stream);
     if (rc) return rc;
   }
-  if (atomic_mask)
-    return launch_backward_atomic(grid, atomic_mask, x, d_out, n, dout_level_stride,
-                                  dout_row_stride, dout_feat_stride, d_table,
+  if (atomic_mask && phase != 1)
+    return launch_backward_atomic(grid, atomic_mask, x, d_out, n, sl, sr, sf, d_table,
                                   (hipStream_t)stream);
   return MRI_OK;
+}
+}  // namespace
+
+extern "C" int mri_hashgrid_backward_prepare(const mri_grid_desc* grid, const float* x, int64_t n,
+                                             int32_t method, void* workspace,
+                                             int64_t workspace_bytes, void* stream) {
+  return backward_impl(grid, x, nullptr, n, 0, 0, 0, nullptr, method, 1, workspace,
+                       workspace_bytes, stream);
+}
+
+extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
+                                     const float* d_out, int64_t n, int64_t dout_level_stride,
+                                     int64_t dout_row_stride, int64_t dout_feat_stride,
+                                     float* d_table, int32_t method, void* workspace,
+                                     int64_t workspace_bytes_given, void* stream) {
+  const int phase = (method & MRI_BWD_PREPARED) ? 2 : 0;
+  return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
+                       d_table, method & ~MRI_BWD_PREPARED, phase, workspace,
+                       workspace_bytes_given, stream);
 }

@@ -103,8 +103,21 @@ def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
     return ws
 
 
+def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, stream=None):
+    """First stage of the binned backward (record counts per table slice): needs only `x`, so
+    it can be queued on a side stream while the forward pass runs.  Follow with
+    hashgrid_backward(..., prepared=True)."""
+    _gpu(x)
+    n = x.shape[0]
+    ws = backward_workspace(desc, n, x.device)
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    _lib.call("mri_hashgrid_backward_prepare", C.byref(desc), _ptr(x), n, method, _ptr(ws),
+              ws.numel() * 8, st)
+
+
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
-                      d_table: torch.Tensor, feature_major: bool = False, method: int = 0):
+                      d_table: torch.Tensor, feature_major: bool = False, method: int = 0,
+                      prepared: bool = False):
     """d_table += scatter of d_out (accumulates)."""
     _gpu(x, d_out, d_table)
     x = _rowmajor(x).contiguous()
@@ -113,8 +126,9 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
         d_out = d_out.contiguous()
     sl, sr, sf = _enc_strides(desc, n, feature_major)
     ws = backward_workspace(desc, n, x.device) if method != 1 else None
+    flags = method | (_lib.BWD_PREPARED if prepared else 0)
     _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
-              _ptr(d_table), method, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
+              _ptr(d_table), flags, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
               _stream())
     return d_table
 

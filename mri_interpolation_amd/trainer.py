@@ -85,6 +85,11 @@ class FusedStep:
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
         self.grad_buckets = 1 if world == 1 else 4
         self._bucket_cache = None
+        # Single launch of the table gradient: its counting stage depends on the coordinates
+        # only, so it is queued on a side stream and overlaps the forward pass / decoder.
+        self.overlap_count = True
+        self._side = None
+        self._counted = False
 
     def _tiny_mlp_plan(self):
         """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
@@ -189,8 +194,11 @@ class FusedStep:
         """Table gradient; with several ranks, reduce each finished level group right away."""
         enc, n = self.encoder, coords.shape[0]
         if self.world == 1 or self.grad_buckets <= 1:
+            if self._counted:
+                torch.cuda.current_stream().wait_stream(self._side)
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
-                                  method=self.bwd_method)
+                                  method=self.bwd_method, prepared=self._counted)
+            self._counted = False
             return []
         pending = []
         rows_per_level = enc.n_features_per_level
@@ -247,6 +255,15 @@ class FusedStep:
 
     def train_step(self, coords, target) -> torch.Tensor:
         """One optimisation step; returns the (device) loss scalar of this rank's batch."""
+        if (self.encoder is not None and self.overlap_count and self.bwd_method != 1
+                and (self.world == 1 or self.grad_buckets <= 1)):
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=coords.device)
+            # after the coordinates exist and after the previous step's backward released the
+            # workspace (both are earlier work of the current stream)
+            self._side.wait_stream(torch.cuda.current_stream())
+            ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side)
+            self._counted = True
         _, ws = self.forward(coords, train=True)
         self._pending = []
         self.backward(coords, target, ws)
