@@ -71,7 +71,9 @@ struct GemmArgs {
   const float* deriv_in;
   int64_t ldd_in;
   // EPI_ATOMIC
-  float* rowsum_out;  // += sum_c P(i, c) for blocks with blockIdx.y == 0 (d_bias)
+  float* rowsum_out;  // += sum_c P(i, c) for the workgroups of column tile 0 (d_bias)
+  int gj;             // number of column tiles (set by launch_cfg)
+  int xcd_order;      // tile order described in gemm_kernel (set by launch_cfg)
 };
 
 template <int O>
@@ -180,8 +182,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int64_t i0 = (int64_t)blockIdx.x * BI, j0 = (int64_t)blockIdx.y * BJ;
-  const int64_t c_begin = (int64_t)blockIdx.z * a.c_per_split;
+  // XCD-aware tile order (speed only): workgroups b and b + 8 share an XCD (round-robin
+  // dispatch), so the gj column tiles of one row block are given ids b, b + 8, ...: they run
+  // at about the same time on the SAME XCD and the second one finds the row block's operand
+  // tile in that L2 instead of fetching it from HBM again.
+  // Only for many row blocks: with a handful (weight gradients), padding to groups of 8 would
+  // leave whole XCDs without work (and ordering the tiles of one batch split onto one XCD
+  // measured no gain there).
+  const int64_t b = blockIdx.x;
+  const int gj = a.gj;
+  int64_t ti_blk;
+  const int64_t split = blockIdx.z;
+  int tj_blk;
+  if (a.xcd_order == 1) {
+    ti_blk = (b / (8 * gj)) * 8 + b % 8;
+    tj_blk = (int)((b / 8) % gj);
+    if (ti_blk * BI >= a.I) return;  // padding of the last group of 8 row blocks
+  } else {
+    ti_blk = b / gj;
+    tj_blk = (int)(b % gj);
+  }
+  const int64_t i0 = ti_blk * BI, j0 = (int64_t)tj_blk * BJ;
+  const int64_t c_begin = split * a.c_per_split;
   const int64_t c_end = min(a.C, c_begin + a.c_per_split);
 
   // per-lane fragment addresses inside the two images
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
   float rowsum = 0.f;
-  const bool want_rowsum = EPI == EPI_ATOMIC && a.rowsum_out != nullptr && blockIdx.y == 0;
+  const bool want_rowsum = EPI == EPI_ATOMIC && a.rowsum_out != nullptr && tj_blk == 0;
 
   TileRegs<BI> pr;
   TileRegs<BJ> qr;
@@ -362,9 +384,12 @@ template <int WI, int WJ, int TI, int TJ, int EPI>
 int launch_cfg(GemmArgs& a, int splits, hipStream_t st) {
   constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
   const int64_t gi = ceil_div(a.I, BI), gj = ceil_div(a.J, BJ);
-  if (gi >= (1ll << 31) || gj > 65535 || splits > 65535)
+  a.gj = (int)gj;
+  a.xcd_order = (gi >= 64 && gj > 1) ? 1 : 0;
+  const int64_t blocks = a.xcd_order ? ceil_div(gi, 8) * 8 * gj : gi * gj;
+  if (blocks >= (1ll << 31) || splits > 65535)
     return fail(MRI_ERR_INVALID_ARGUMENT, "gemm grid too large");
-  hipLaunchKernelGGL((gemm_kernel<WI, WJ, TI, TJ, EPI>), dim3((unsigned)gi, (unsigned)gj, splits),
+  hipLaunchKernelGGL((gemm_kernel<WI, WJ, TI, TJ, EPI>), dim3((unsigned)blocks, 1, splits),
                      dim3(kThreads), 0, st, a);
   return check_launch("gemm_kernel");
 }
