@@ -72,19 +72,39 @@ template <int TI, int TJ>
 __device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __restrict__ a,
                                        int a_tile, int a_step, const float* __restrict__ b,
                                        int b_tile, int b_step, int steps) {
-#pragma unroll 4
-  for (int s = 0; s < steps; ++s) {
-    float av[TI], bv[TJ];
+  // Software pipeline over groups of U contraction pairs: the LDS reads of group g+1 are
+  // issued before the MFMAs of group g, so a wave that is alone on its matrix pipe does not
+  // expose the ds_read latency once per group.  `steps` is a multiple of U at every call site.
+  constexpr int U = 4;
+  float av[2][U][TI], bv[2][U][TJ];
+  auto fetch = [&](int buf, int s0) {
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) av[ti] = a[ti * a_tile + s * a_step];
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) bv[tj] = b[tj * b_tile + s * b_step];
+      for (int ti = 0; ti < TI; ++ti) av[buf][u][ti] = a[ti * a_tile + (s0 + u) * a_step];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+      for (int tj = 0; tj < TJ; ++tj) bv[buf][u][tj] = b[tj * b_tile + (s0 + u) * b_step];
+    }
+  };
+  auto compute = [&](int buf) {
 #pragma unroll
-      for (int tj = 0; tj < TJ; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][ti], bv[buf][u][tj],
+                                                             acc[ti][tj], 0, 0, 0);
+  };
+  fetch(0, 0);
+  int s = 0;
+  for (; s + 2 * U <= steps; s += 2 * U) {
+    fetch(1, s + U);
+    compute(0);
+    if (s + 2 * U < steps) fetch(0, s + 2 * U);
+    compute(1);
   }
+  if (s < steps) compute(0);  // steps = odd multiple of U
 }
 
 template <int TI, int TJ>
