@@ -115,11 +115,18 @@ def main():
                     help="total training steps before the PSNR evaluation (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bwd-method", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[],
+                    help="library tuning option name=value (mri_set_option), repeatable")
+    ap.add_argument("--grad-buckets", type=int, default=0,
+                    help="level groups of the table-gradient kernels (0 = default)")
     args = ap.parse_args()
 
     import torch
     from mri_interpolation_amd import _lib, datamodules, parallel, trainer
     _lib.load()  # no fallback: fail before touching the GPU if the HIP library is missing
+    for item in args.opt:
+        name, value = item.split("=")
+        _lib.set_option(name, int(value))
 
     rank, world, local = parallel.init()
     if world != args.gpus:
@@ -138,6 +145,8 @@ def main():
     opt = model.configure_optimizers()
     step = trainer.FusedStep(model, opt, world)
     step.bwd_method = args.bwd_method
+    if args.grad_buckets:
+        step.grad_buckets = args.grad_buckets
     n_params = sum(p.numel() for p in model.parameters())
     coords = torch.empty(w["batch"], 3, device=dev)
     target = torch.empty(w["batch"], 1, device=dev)

@@ -67,8 +67,8 @@ typedef struct mri_grid_desc {
 /* Library / build identification: "mri_inr <version> gfx950". */
 const char* mri_version(void);
 const char* mri_last_error(void);
-/* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level"
- * n); results stay within fp32 summation-order noise. */
+/* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level" n,
+ * "bwd_dense_max_parts" n); results stay within fp32 summation-order noise. */
 int mri_set_option(const char* name, int32_t value);
 
 /* ---- hash-grid encoding --------------------------------------------------------------
@@ -94,10 +94,9 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  *   method 0 = choose per level; 1 = global float atomics; 2 = LDS owner-computes scan with
  *   64-bit fixed-point accumulation (bitwise reproducible gradients).
  *   workspace: device scratch of at least mri_hashgrid_backward_workspace_bytes(grid, n)
- *   bytes, 16-byte aligned, ZERO-INITIALISED by the caller once; every call hands its
- *   zero-between-calls regions back zeroed, so it can be reused across steps without clearing.
- *   A buffer shared by calls with different grids / n must be sized for the largest of them
- *   and always be passed with the same workspace_bytes.  May be NULL for method 1.
+ *   bytes, 16-byte aligned; no initialisation needed (the call clears what it needs), it
+ *   may be shared by calls with different grids / n on the same stream.  May be NULL for
+ *   method 1.
  */
 int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n);
 /* Optional split: the first stage of the binned backward (counting the records per table

@@ -22,6 +22,7 @@
 //                 fixed point (v * 2^e as int64, ds_add_u64), converts once and adds the slice
 //                 to d_table with coalesced accesses
 //   6. finalize   bins that were cut into several entry ranges meet in an int64 workspace.
+// Coarse levels (few slices) skip 2-5: dense_level_kernel evaluates every corner per slice instead.
 // Integer addition is associative: the table gradient is BITWISE REPRODUCIBLE (independent of
 // scheduling and of the order the records landed in), and more accurate than an f32 running sum
 // (>= 40 fraction bits below max|g|; |sum| <= n * max|g| < 2^61 cannot overflow).
@@ -56,11 +57,12 @@ struct BinPlan {
 };
 
 struct Workspace {  // carved out of the caller's buffer
-  uint32_t* max_bits;   // [kHeaderWords]       zero between calls
-  uint32_t* cursor;     // [kMaxBins]           zero between calls
+  uint32_t* max_bits;   // [kHeaderWords]       cleared at the start of every call
+  uint32_t* cursor;     // [kMaxBins]           cleared at the start of every call
   uint32_t* offsets;    // [kMaxBins + 1]       bin starts, multiples of 4 records
   uint32_t* counts;     // [kMaxBins]           records per bin
-  unsigned long long* partial;  // [ws_words]   zero between calls
+  unsigned long long* partial;  // [ws_words]   cleared at the start of every call
+  int64_t partial_words;
   uint32_t* rec_slot;   // [records]
   float* rec_val;       // [F][records]
   int64_t records;
@@ -334,43 +336,116 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   }
 }
 
+// ------------------------------------------------------------------------- coarse levels
+// A level whose table is cut into only a few slices does not need records at all: a workgroup
+// (level, slice, coordinate range) can afford to evaluate the corners of every coordinate of its
+// range and add the ones that fall into its slice straight into LDS -- the redundancy is the
+// number of slices (<= bwd_dense_max_parts), against 24 bytes of record traffic per corner.
+// Ranges meet in the int64 workspace like the entry ranges of the binned levels.
+template <int F>
+__global__ __launch_bounds__(256) void dense_absmax_kernel(const BinPlan plan,
+                                                           const float* __restrict__ d_out,
+                                                           int64_t n, int64_t sl, int64_t sr,
+                                                           int64_t sf,
+                                                           uint32_t* __restrict__ max_bits) {
+  __shared__ uint32_t wg_max;
+  const int level = plan.level_of[blockIdx.y];
+  const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  if (threadIdx.x == 0) wg_max = 0u;
+  __syncthreads();
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(gl[i * sr + f * sf]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(max_bits + level, wg_max);
+}
+
+template <int D, int F>
+__global__ __launch_bounds__(kAccThreads) void dense_level_kernel(
+    const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
+    const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
+    const uint32_t* __restrict__ max_bits, unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long acc[kAccWords];
+  const int b = blockIdx.x;
+  int e = 0;
+  while (e + 1 < plan.n_entries && b >= plan.acc_start[e + 1]) ++e;
+  const int level = plan.level_of[e];
+  const int splits = plan.splits[e];
+  const int part = (b - plan.acc_start[e]) / splits, split = (b - plan.acc_start[e]) % splits;
+  const uint32_t size = tab.size[level], magic = tab.magic[level];
+  const bool pow2 = tab.pow2[level] != 0;
+  const uint32_t slots = 1u << plan.log2_slots;
+  const uint32_t base = (uint32_t)part * slots;
+  const uint32_t count = min(slots, size - base);
+  const int64_t per = (n + splits - 1) / splits;
+  const int64_t i_begin = (int64_t)split * per, i_end = min(n, i_begin + per);
+
+  for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
+  __syncthreads();
+  const int ex = level_exponent(max_bits[level], n);
+  const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
+  const float* __restrict__ res = tab.res[level];
+  const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kAccThreads) {
+    const Cell<D> c = locate<D>(x, i, res);
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = gl[i * sr + f * sf];
+#pragma unroll
+    for (int nb = 0; nb < (1 << D); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, nb, h, w);
+      const uint32_t rel = slot_of(h, size, magic, pow2) - base;
+      if (rel < count) {
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          atomicAdd(&acc[rel * F + f], (unsigned long long)to_fixed(g[f] * w, scale_hi));
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* __restrict__ dst = partial + plan.ws_offset[e] + (uint64_t)base * F;
+  for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
+    if (acc[s]) atomicAdd(dst + s, acc[s]);
+}
+
 // ------------------------------------------------------------------------------ 6. finalize
 __global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, const BinPlan plan,
                                                            int F, int64_t n,
                                                            float* __restrict__ d_table,
                                                            const uint32_t* __restrict__ max_bits,
-                                                           unsigned long long* __restrict__ partial) {
+                                                           const unsigned long long* __restrict__ partial) {
   const int e = blockIdx.y;
   if (plan.ws_offset[e] < 0) return;
   const int level = plan.level_of[e];
   const double inv_scale = __builtin_ldexp(1.0, -level_exponent(max_bits[level], n));
   const uint64_t words = (uint64_t)tab.size[level] * F;
-  unsigned long long* __restrict__ src = partial + plan.ws_offset[e];
+  const unsigned long long* __restrict__ src = partial + plan.ws_offset[e];
   float* __restrict__ dst = d_table + tab.offset[level] * F;
   for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < words;
        s += (uint64_t)gridDim.x * 256) {
     const long long v = (long long)src[s];
-    if (v) {
-      dst[s] += (float)((double)v * inv_scale);
-      src[s] = 0ull;
-    }
+    if (v) dst[s] += (float)((double)v * inv_scale);
   }
-}
-
-__global__ __launch_bounds__(256) void bin_reset_kernel(uint32_t* __restrict__ max_bits,
-                                                        uint32_t* __restrict__ cursor,
-                                                        int total_bins) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < kHeaderWords) max_bits[t] = 0u;
-  if (t < total_bins) cursor[t] = 0u;
 }
 
 // ------------------------------------------------------------------------------ host side
 // Which levels take the binned path and how the kernels are cut; returns false if none does.
-bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uint32_t& atomic_mask,
-               int64_t& ws_words, int64_t& records, int& acc_blocks) {
+bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, BinPlan& dense,
+               int& dense_blocks, uint32_t& atomic_mask, int64_t& ws_words, int64_t& records,
+               int& acc_blocks) {
   const int F = g->n_features, D = g->dim;
   plan = BinPlan{};
+  dense = BinPlan{};
+  dense_blocks = 0;
   atomic_mask = 0;
   ws_words = records = 0;
   acc_blocks = 0;
@@ -386,6 +461,20 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uin
                         (method == 2 || (method == 0 && parts <= options().bwd_lds_max_parts));
     if (!binned) {
       atomic_mask |= 1u << l;
+      continue;
+    }
+    if (parts <= options().bwd_dense_max_parts) {  // coarse level: no records, see dense_level_kernel
+      const int e = dense.n_entries++;
+      int splits = std::max(1, target / parts);
+      splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, n / 2048));
+      dense.level_of[e] = l;
+      dense.parts[e] = parts;
+      dense.splits[e] = splits;
+      dense.acc_start[e] = dense_blocks;
+      dense_blocks += parts * splits;
+      dense.acc_start[e + 1] = dense_blocks;
+      dense.ws_offset[e] = ws_words;
+      ws_words += (int64_t)g->table_size[l] * F;
       continue;
     }
     const int e = plan.n_entries++;
@@ -408,7 +497,8 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, uin
     records += n << D;
   }
   records = (records + 4 * (int64_t)plan.total_bins + 3) / 4 * 4;  // bins are padded to 4 records
-  return plan.n_entries > 0;
+  dense.log2_slots = plan.log2_slots;
+  return plan.n_entries > 0 || dense.n_entries > 0;
 }
 
 int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
@@ -416,10 +506,7 @@ int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
          ws_words * 8 + records * 4 * (1 + F) + 64;
 }
 
-// Fixed-position regions first, the record area next, and the zero-between-calls int64 area
-// anchored at the END of the caller's buffer: calls with different level sets / batch sizes that
-// share one buffer (of one size) then always find their int64 area inside memory that only ever
-// holds int64 partial sums, never another call's records.
+// Fixed-position regions first, the record area next, the int64 area at the END of the buffer.
 Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t records, int F) {
   Workspace w{};
   char* p = static_cast<char*>(base);
@@ -437,17 +524,37 @@ Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t recor
   w.records = records;
   const int64_t tail = (total_bytes - ws_words * 8) & ~int64_t(15);
   w.partial = reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + tail);
+  w.partial_words = ws_words;
   return w;
 }
 
 template <int D, int F>
 struct BinnedLaunch {
-  static int run(const LevelTab& tab, const BinPlan& plan, const Workspace& w, int n_levels,
-                 int acc_blocks, bool any_split, int phase, const float* x, const float* d_out,
-                 int64_t n, int64_t sl, int64_t sr, int64_t sf, float* d_table, hipStream_t st) {
+  static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense, int dense_blocks,
+                 const Workspace& w, int n_levels, int acc_blocks, bool any_split, int phase,
+                 const float* x, const float* d_out, int64_t n, int64_t sl, int64_t sr,
+                 int64_t sf, float* d_table, hipStream_t st) {
     // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
     // forward pass); 2: the rest, after a phase-1 call on the same workspace
     if constexpr (D <= 4 && F <= 4) {
+      // The zero-on-entry regions are cleared here, per call: a buffer shared by calls with
+      // different level sets or batch sizes then needs no invariant across calls.
+      if (phase != 2) {
+        (void)hipMemsetAsync(w.max_bits, 0, kHeaderWords * 4, st);
+        if (plan.total_bins > 0) (void)hipMemsetAsync(w.cursor, 0, (size_t)plan.total_bins * 4, st);
+      }
+      if (phase != 1 && w.partial_words > 0)
+        (void)hipMemsetAsync(w.partial, 0, (size_t)w.partial_words * 8, st);
+      if (dense.n_entries > 0 && phase != 1) {
+        hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
+                           dense, d_out, n, sl, sr, sf, w.max_bits);
+        hipLaunchKernelGGL((dense_level_kernel<D, F>), dim3((unsigned)dense_blocks),
+                           dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
+                           w.max_bits, w.partial);
+        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, dense.n_entries), dim3(256), 0, st, tab,
+                           dense, F, n, d_table, w.max_bits, w.partial);
+      }
+      if (plan.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
       const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
       const dim3 count_grid((unsigned)ceil_div(n, plan.coords_per_block * kCountChunks),
                             plan.n_entries);
@@ -467,8 +574,6 @@ struct BinnedLaunch {
       if (any_split)
         hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, plan.n_entries), dim3(256), 0, st, tab,
                            plan, F, n, d_table, w.max_bits, w.partial);
-      hipLaunchKernelGGL(bin_reset_kernel, dim3((unsigned)ceil_div(kMaxBins, 256)), dim3(256), 0,
-                         st, w.max_bits, w.cursor, plan.total_bins);
       return check_launch("hashgrid backward (binned)");
     } else {
       return fail(MRI_ERR_UNSUPPORTED, "binned backward supports dim <= 4, n_features <= 4");
@@ -483,11 +588,12 @@ using namespace mri;
 
 extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t n) {
   if (validate(grid)) return -1;
-  BinPlan plan;
+  BinPlan plan, dense;
   uint32_t mask;
   int64_t words, records;
-  int acc_blocks;
-  make_plan(grid, std::max<int64_t>(n, 1), 2, plan, mask, words, records, acc_blocks);
+  int acc_blocks, dense_blocks;
+  make_plan(grid, std::max<int64_t>(n, 1), 2, plan, dense, dense_blocks, mask, words, records,
+            acc_blocks);
   return workspace_bytes(words, records, grid->n_features);
 }
 
@@ -501,11 +607,12 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
   if (n == 0) return MRI_OK;
   MRI_REQUIRE(x && (phase == 1 || (d_out && d_table)), "NULL device pointer");
   const int F = grid->n_features;
-  BinPlan plan;
+  BinPlan plan, dense;
   uint32_t atomic_mask;
   int64_t ws_words, records;
-  int acc_blocks;
-  if (make_plan(grid, n, method, plan, atomic_mask, ws_words, records, acc_blocks)) {
+  int acc_blocks, dense_blocks;
+  if (make_plan(grid, n, method, plan, dense, dense_blocks, atomic_mask, ws_words, records,
+                acc_blocks)) {
     MRI_REQUIRE(records < (1ll << 32), "too many gradient records (%lld)", (long long)records);
     const int64_t need = workspace_bytes(ws_words, records, F);
     MRI_REQUIRE(workspace != nullptr && workspace_bytes_given >= need,
@@ -516,9 +623,11 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
                 "workspace must be 16-byte aligned");
     const Workspace w = carve(workspace, workspace_bytes_given, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
-    int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, w, grid->n_levels, acc_blocks,
-                                    ws_words > 0, phase, x, d_out, n, sl, sr, sf, d_table,
-                                    (hipStream_t)stream);
+    bool any_split = false;
+    for (int e = 0; e < plan.n_entries; ++e) any_split |= plan.ws_offset[e] >= 0;
+    int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, dense_blocks, w,
+                                    grid->n_levels, acc_blocks, any_split, phase, x, d_out, n, sl,
+                                    sr, sf, d_table, (hipStream_t)stream);
     if (rc) return rc;
   }
   if (atomic_mask && phase != 1)

@@ -89,7 +89,7 @@ def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
     return out
 
 
-_bwd_workspace = {}  # device index -> zero-initialised scratch (the library re-zeroes it)
+_bwd_workspace = {}  # device index -> scratch (the library clears what it needs per call)
 
 
 def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
@@ -98,7 +98,7 @@ def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
         _lib.check(-1, "mri_hashgrid_backward_workspace_bytes")
     ws = _bwd_workspace.get(device.index)
     if ws is None or ws.numel() * 8 < need:
-        ws = torch.zeros((need + 7) // 8, dtype=torch.int64, device=device)
+        ws = torch.empty((need + 7) // 8, dtype=torch.int64, device=device)
         _bwd_workspace[device.index] = ws
     return ws
 

@@ -193,7 +193,7 @@ class FusedStep:
     def _hash_backward(self, coords, d_enc):
         """Table gradient; with several ranks, reduce each finished level group right away."""
         enc, n = self.encoder, coords.shape[0]
-        if self.world == 1 or self.grad_buckets <= 1:
+        if self.grad_buckets <= 1:
             if self._counted:
                 torch.cuda.current_stream().wait_stream(self._side)
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
@@ -256,7 +256,7 @@ class FusedStep:
     def train_step(self, coords, target) -> torch.Tensor:
         """One optimisation step; returns the (device) loss scalar of this rank's batch."""
         if (self.encoder is not None and self.overlap_count and self.bwd_method != 1
-                and (self.world == 1 or self.grad_buckets <= 1)):
+                and self.grad_buckets <= 1):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=coords.device)
             # after the coordinates exist and after the previous step's backward released the
