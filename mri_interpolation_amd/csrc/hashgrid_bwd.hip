@@ -14,8 +14,9 @@
 // So the contributions are first ROUTED to the workgroup that owns their table slice, then
 // summed there with 64-bit integer LDS atomics:
 //   1. (in 4.)    per-level max|d_out|  -> per-level power-of-two scale 2^e (on device)
-//   2. count      histogram of contributions per bin (bin = level x slice of kAccWords/F slots)
-//   3. prefix     exclusive scan of the bin counts -> bin offsets
+//   2. count      per 512-coordinate chunk: corners per bin (bin = level x slice of kAccWords/F
+//                 slots); then per bin an exclusive scan over the chunks (2b)
+//   3. prefix     exclusive scan of the bin totals -> bin offsets
 //   4. scatter    recompute the corners, stage (slot, w*g[0..F)) records in LDS grouped by
 //                 bin, copy them out in bin-contiguous runs (coalesced)
 //   5. accumulate one workgroup per bin (big bins: per entry range) adds its records into LDS as
@@ -39,7 +40,6 @@ constexpr int kAccThreads = 1024;
 constexpr int kStageWords = 12288;  // 48 KiB LDS staging buffer of the scatter kernel (2 workgroups/CU)
 constexpr int kBinThreads = 512;
 constexpr int kMaxParts = 256;        // slices per level handled by the binned path
-constexpr int kCountChunks = 8;       // the count kernel walks 8 scatter chunks per workgroup
 constexpr int kHeaderWords = 64;      // per-level max|g| bits
 constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
 
@@ -61,6 +61,8 @@ struct Workspace {  // carved out of the caller's buffer
   uint32_t* cursor;     // [kMaxBins]           cleared at the start of every call
   uint32_t* offsets;    // [kMaxBins + 1]       bin starts, multiples of 4 records
   uint32_t* counts;     // [kMaxBins]           records per bin
+  uint32_t* chunk_hist;  // [total_bins][chunks] corners of a chunk per bin
+  uint32_t* chunk_base;  // [total_bins][chunks] where the chunk's run starts inside the bin
   unsigned long long* partial;  // [ws_words]   cleared at the start of every call
   int64_t partial_words;
   uint32_t* rec_slot;   // [records]
@@ -121,8 +123,9 @@ template <int D, int F, bool SCATTER>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
     const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
-    uint32_t* __restrict__ cursor, uint32_t* __restrict__ rec_slot, float* __restrict__ rec_val,
-    int64_t records, uint32_t* __restrict__ max_bits) {
+    uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_base,
+    const uint32_t* __restrict__ offsets, int chunks, uint32_t* __restrict__ rec_slot,
+    float* __restrict__ rec_val, int64_t records, uint32_t* __restrict__ max_bits) {
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
@@ -136,42 +139,44 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   const bool pow2 = tab.pow2[level] != 0;
   const uint32_t slot_mask = (1u << plan.log2_slots) - 1u;
   const float* __restrict__ res = tab.res[level];
-  const int chunk = SCATTER ? plan.coords_per_block : plan.coords_per_block * kCountChunks;
-  const int64_t i_begin = (int64_t)blockIdx.x * chunk;
-  const int64_t i_end = min(n, i_begin + chunk);
-
-  for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
-  if (threadIdx.x == 0) wg_max = 0u;
-  __syncthreads();
-
-  // pass A: histogram of the corners' bins
-  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
-    uint32_t h0[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) h0[d] = (uint32_t)(int)(x[i * D + d] * res[d]) * kPrimes[d];
-#pragma unroll
-    for (int nb = 0; nb < (1 << D); ++nb) {
-      uint32_t h = 0;
-#pragma unroll
-      for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
-      atomicAdd(&hist[slot_of(h, size, magic, pow2) >> plan.log2_slots], 1u);
-    }
-  }
-  __syncthreads();
+  const int64_t i_begin = (int64_t)blockIdx.x * plan.coords_per_block;
+  const int64_t i_end = min(n, i_begin + plan.coords_per_block);
+  // per-(bin, chunk) tables, bin-major: entry (bin, chunk) at bin * chunks + chunk
+  const uint64_t row0 = (uint64_t)plan.bin_start[e] * chunks + blockIdx.x;
 
   if (!SCATTER) {
+    // count: how many corners of this chunk fall into each slice of the level
+    for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
+    __syncthreads();
+    for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
+      uint32_t h0[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) h0[d] = (uint32_t)(int)(x[i * D + d] * res[d]) * kPrimes[d];
+#pragma unroll
+      for (int nb = 0; nb < (1 << D); ++nb) {
+        uint32_t h = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
+        atomicAdd(&hist[slot_of(h, size, magic, pow2) >> plan.log2_slots], 1u);
+      }
+    }
+    __syncthreads();
     for (int p = threadIdx.x; p < parts; p += kBinThreads)
-      if (hist[p]) atomicAdd(cursor + plan.bin_start[e] + p, hist[p]);
+      chunk_hist[row0 + (uint64_t)p * chunks] = hist[p];
     return;
   }
 
-  // reserve a run in every bin, and lay the runs out back to back in the staging buffer
+  // scatter: this chunk's run inside every bin was fixed by the count + scan stages (no
+  // atomics, and the record order is the same on every run)
+  for (int p = threadIdx.x; p < parts; p += kBinThreads) {
+    hist[p] = chunk_hist[row0 + (uint64_t)p * chunks];
+    global_base[p] = offsets[plan.bin_start[e] + p] + chunk_base[row0 + (uint64_t)p * chunks];
+  }
+  if (threadIdx.x == 0) wg_max = 0u;
+  __syncthreads();
   if (threadIdx.x < 64) wave_exclusive_scan<kMaxParts / 64>(hist, local_off, parts);
   __syncthreads();
-  for (int p = threadIdx.x; p < parts; p += kBinThreads) {
-    global_base[p] = hist[p] ? atomicAdd(cursor + plan.bin_start[e] + p, hist[p]) : 0u;
-    hist[p] = 0u;  // becomes the fill counter of pass B
-  }
+  for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;  // fill counters
   __syncthreads();
 
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
@@ -221,6 +226,31 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
         rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
     }
   }
+}
+
+// ----------------------------------------------------------------------------- 2b. chunk scan
+// One wave per bin: exclusive scan of the bin's per-chunk counts (where each chunk's run starts
+// inside the bin) and the bin total.
+__global__ __launch_bounds__(64) void bin_chunk_scan_kernel(const uint32_t* __restrict__ chunk_hist,
+                                                            uint32_t* __restrict__ chunk_base,
+                                                            uint32_t* __restrict__ cursor,
+                                                            int chunks) {
+  const uint64_t row = (uint64_t)blockIdx.x * chunks;
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  for (int c0 = 0; c0 < chunks; c0 += 64) {
+    const int c = c0 + lane;
+    const uint32_t v = c < chunks ? chunk_hist[row + c] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (c < chunks) chunk_base[row + c] = carry + incl - v;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cursor[blockIdx.x] = carry;
 }
 
 // ------------------------------------------------------------------------------ 3. prefix
@@ -501,13 +531,19 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, Bin
   return plan.n_entries > 0 || dense.n_entries > 0;
 }
 
-int64_t workspace_bytes(int64_t ws_words, int64_t records, int F) {
+int64_t chunk_table_words(const BinPlan& plan, int64_t n) {
+  const int64_t chunks = plan.coords_per_block > 0 ? ceil_div(n, plan.coords_per_block) : 0;
+  return (int64_t)plan.total_bins * chunks + 4;
+}
+
+int64_t workspace_bytes(const BinPlan& plan, int64_t n, int64_t ws_words, int64_t records, int F) {
   return (int64_t)kHeaderWords * 4 + 2 * (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 12 +
-         ws_words * 8 + records * 4 * (1 + F) + 64;
+         2 * chunk_table_words(plan, n) * 4 + ws_words * 8 + records * 4 * (1 + F) + 64;
 }
 
 // Fixed-position regions first, the record area next, the int64 area at the END of the buffer.
-Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t records, int F) {
+Workspace carve(void* base, int64_t total_bytes, const BinPlan& plan, int64_t n, int64_t ws_words,
+                int64_t records, int F) {
   Workspace w{};
   char* p = static_cast<char*>(base);
   w.max_bits = reinterpret_cast<uint32_t*>(p);
@@ -518,6 +554,11 @@ Workspace carve(void* base, int64_t total_bytes, int64_t ws_words, int64_t recor
   p += (int64_t)(kMaxBins + 1) * 4 + 12;  // keeps the following fields 16-byte aligned
   w.counts = reinterpret_cast<uint32_t*>(p);
   p += (int64_t)kMaxBins * 4;
+  const int64_t table = chunk_table_words(plan, n) / 4 * 4;  // keeps 16-byte alignment
+  w.chunk_hist = reinterpret_cast<uint32_t*>(p);
+  p += table * 4;
+  w.chunk_base = reinterpret_cast<uint32_t*>(p);
+  p += table * 4;
   w.rec_slot = reinterpret_cast<uint32_t*>(p);
   p += records * 4;
   w.rec_val = reinterpret_cast<float*>(p);
@@ -541,7 +582,6 @@ struct BinnedLaunch {
       // different level sets or batch sizes then needs no invariant across calls.
       if (phase != 2) {
         (void)hipMemsetAsync(w.max_bits, 0, kHeaderWords * 4, st);
-        if (plan.total_bins > 0) (void)hipMemsetAsync(w.cursor, 0, (size_t)plan.total_bins * 4, st);
       }
       if (phase != 1 && w.partial_words > 0)
         (void)hipMemsetAsync(w.partial, 0, (size_t)w.partial_words * 8, st);
@@ -555,19 +595,21 @@ struct BinnedLaunch {
                            dense, F, n, d_table, w.max_bits, w.partial);
       }
       if (plan.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
-      const dim3 bin_grid((unsigned)ceil_div(n, plan.coords_per_block), plan.n_entries);
-      const dim3 count_grid((unsigned)ceil_div(n, plan.coords_per_block * kCountChunks),
-                            plan.n_entries);
+      const int chunks = (int)ceil_div(n, plan.coords_per_block);
+      const dim3 bin_grid((unsigned)chunks, plan.n_entries);
       if (phase != 2) {
-        hipLaunchKernelGGL((bin_kernel<D, F, false>), count_grid, dim3(kBinThreads), 0, st, tab,
-                           plan, x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val,
-                           w.records, w.max_bits);
+        hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
+                           x, d_out, n, sl, sr, sf, w.chunk_hist, w.chunk_base, w.offsets, chunks,
+                           w.rec_slot, w.rec_val, w.records, w.max_bits);
+        hipLaunchKernelGGL(bin_chunk_scan_kernel, dim3((unsigned)plan.total_bins), dim3(64), 0, st,
+                           w.chunk_hist, w.chunk_base, w.cursor, chunks);
         hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
                            w.counts, plan.total_bins);
       }
       if (phase == 1) return check_launch("hashgrid backward (count)");
       hipLaunchKernelGGL((bin_kernel<D, F, true>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
-                         x, d_out, n, sl, sr, sf, w.cursor, w.rec_slot, w.rec_val, w.records, w.max_bits);
+                         x, d_out, n, sl, sr, sf, w.chunk_hist, w.chunk_base, w.offsets, chunks,
+                         w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
                          dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.counts, w.rec_slot,
                          w.rec_val, w.records, w.max_bits, d_table, w.partial);
@@ -594,7 +636,7 @@ extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* gr
   int acc_blocks, dense_blocks;
   make_plan(grid, std::max<int64_t>(n, 1), 2, plan, dense, dense_blocks, mask, words, records,
             acc_blocks);
-  return workspace_bytes(words, records, grid->n_features);
+  return workspace_bytes(plan, std::max<int64_t>(n, 1), words, records, grid->n_features);
 }
 
 namespace {
@@ -614,14 +656,14 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
   if (make_plan(grid, n, method, plan, dense, dense_blocks, atomic_mask, ws_words, records,
                 acc_blocks)) {
     MRI_REQUIRE(records < (1ll << 32), "too many gradient records (%lld)", (long long)records);
-    const int64_t need = workspace_bytes(ws_words, records, F);
+    const int64_t need = workspace_bytes(plan, n, ws_words, records, F);
     MRI_REQUIRE(workspace != nullptr && workspace_bytes_given >= need,
                 "hashgrid backward needs a workspace of %lld bytes "
                 "(mri_hashgrid_backward_workspace_bytes), got %lld",
                 (long long)need, (long long)workspace_bytes_given);
     MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                 "workspace must be 16-byte aligned");
-    const Workspace w = carve(workspace, workspace_bytes_given, ws_words, records, F);
+    const Workspace w = carve(workspace, workspace_bytes_given, plan, n, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
     bool any_split = false;
     for (int e = 0; e < plan.n_entries; ++e) any_split |= plan.ws_offset[e] >= 0;
