@@ -104,6 +104,10 @@ int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* grid, int64_t
  * forward pass and then call mri_hashgrid_backward with `method | MRI_BWD_PREPARED` on the same
  * workspace (same grid, n and method; nothing else may use the workspace in between). */
 #define MRI_BWD_PREPARED 16
+/* `method | MRI_BWD_OVERWRITE`: d_table is OVERWRITTEN with the gradient (every row of every
+ * level is written) instead of accumulated into, which saves the caller's memset and the
+ * read half of the accumulation. */
+#define MRI_BWD_OVERWRITE 32
 int mri_hashgrid_backward_prepare(const mri_grid_desc* grid, const float* x, int64_t n,
                                   int32_t method, void* workspace, int64_t workspace_bytes,
                                   void* stream);
@@ -177,6 +181,14 @@ int mri_tiny_mlp_train(const float* x, const float* target, int64_t n, int32_t k
                        float* d_b3, float* d_x /* may be NULL */, float* loss_out,
                        float* y /* may be NULL */, void* workspace, int64_t workspace_bytes,
                        void* stream);
+/* Same, but d_w*, d_b* and loss_out are overwritten instead of accumulated into. */
+int mri_tiny_mlp_train_overwrite(const float* x, const float* target, int64_t n, int32_t k_in,
+                                 int32_t hidden, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, const float* w3,
+                                 const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                 float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                 float* loss_out, float* y, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
 
 /* ---- loss ------------------------------------------------------------------------------
  * F.mse_loss(y, y_pred) (reference models.py:64): loss_out[0] += mean((pred-target)^2)

@@ -12,6 +12,7 @@ MAX_DIM = 7
 ACT_IDENTITY, ACT_RELU, ACT_SINE, ACT_GELU = 0, 1, 2, 3
 DERIV_NONE, DERIV_MUL, DERIV_RELU_MASK = 0, 1, 2
 BWD_PREPARED = 16
+BWD_OVERWRITE = 32
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmri_inr.so")
 
@@ -52,6 +53,8 @@ SIGNATURES = {
     "mri_tiny_mlp_forward": [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "mri_tiny_mlp_train": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                            _P, _P, _P, _P, _P, _P, _I64, _P],
+    "mri_tiny_mlp_train_overwrite": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
     "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],

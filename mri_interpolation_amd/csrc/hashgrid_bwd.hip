@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_slot,
     const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
-    unsigned long long* __restrict__ partial) {
+    unsigned long long* __restrict__ partial, int overwrite) {
   __shared__ unsigned long long acc[kAccWords];
   const int b = blockIdx.x;
   int e = 0;
@@ -302,7 +302,13 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   const uint32_t r_lo = offsets[bin], r_cnt = counts[bin];  // r_lo is a multiple of 4
   const uint32_t per = ((r_cnt + splits - 1) / splits + 3u) & ~3u;
   const uint32_t k_lo = min(r_cnt, (uint32_t)split * per), k_hi = min(r_cnt, k_lo + per);
-  if (k_lo >= k_hi) return;  // nothing routed here (uniform for the workgroup)
+  if (k_lo >= k_hi) {  // nothing routed here (uniform for the workgroup)
+    if (overwrite && plan.ws_offset[e] < 0) {
+      float* __restrict__ dst = d_table + (tab.offset[level] + base) * F;
+      for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) dst[s] = 0.0f;
+    }
+    return;
+  }
 
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
   __syncthreads();
@@ -355,9 +361,14 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   if (ws_off < 0) {  // sole owner of the slice: convert once, add to the f32 gradient
     const double inv_scale = __builtin_ldexp(1.0, -ex);
     float* __restrict__ dst = d_table + (tab.offset[level] + base) * F;
-    for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) {
-      const long long v = (long long)acc[s];
-      if (v) dst[s] += (float)((double)v * inv_scale);
+    if (overwrite) {
+      for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
+        dst[s] = (float)((double)(long long)acc[s] * inv_scale);
+    } else {
+      for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) {
+        const long long v = (long long)acc[s];
+        if (v) dst[s] += (float)((double)v * inv_scale);
+      }
     }
   } else {  // one entry range of a big bin: meet the other ranges in the integer workspace
     unsigned long long* __restrict__ dst = partial + ws_off + (uint64_t)base * F;
@@ -452,7 +463,8 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, c
                                                            int F, int64_t n,
                                                            float* __restrict__ d_table,
                                                            const uint32_t* __restrict__ max_bits,
-                                                           const unsigned long long* __restrict__ partial) {
+                                                           const unsigned long long* __restrict__ partial,
+                                                           int overwrite) {
   const int e = blockIdx.y;
   if (plan.ws_offset[e] < 0) return;
   const int level = plan.level_of[e];
@@ -463,7 +475,10 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, c
   for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < words;
        s += (uint64_t)gridDim.x * 256) {
     const long long v = (long long)src[s];
-    if (v) dst[s] += (float)((double)v * inv_scale);
+    if (overwrite)
+      dst[s] = (float)((double)v * inv_scale);
+    else if (v)
+      dst[s] += (float)((double)v * inv_scale);
   }
 }
 
@@ -573,6 +588,7 @@ template <int D, int F>
 struct BinnedLaunch {
   static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense, int dense_blocks,
                  const Workspace& w, int n_levels, int acc_blocks, bool any_split, int phase,
+                 int overwrite,
                  const float* x, const float* d_out, int64_t n, int64_t sl, int64_t sr,
                  int64_t sf, float* d_table, hipStream_t st) {
     // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
@@ -592,7 +608,7 @@ struct BinnedLaunch {
                            dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
                            w.max_bits, w.partial);
         hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, dense.n_entries), dim3(256), 0, st, tab,
-                           dense, F, n, d_table, w.max_bits, w.partial);
+                           dense, F, n, d_table, w.max_bits, w.partial, overwrite);
       }
       if (plan.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
       const int chunks = (int)ceil_div(n, plan.coords_per_block);
@@ -612,10 +628,10 @@ struct BinnedLaunch {
                          w.rec_slot, w.rec_val, w.records, w.max_bits);
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
                          dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.counts, w.rec_slot,
-                         w.rec_val, w.records, w.max_bits, d_table, w.partial);
+                         w.rec_val, w.records, w.max_bits, d_table, w.partial, overwrite);
       if (any_split)
         hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, plan.n_entries), dim3(256), 0, st, tab,
-                           plan, F, n, d_table, w.max_bits, w.partial);
+                           plan, F, n, d_table, w.max_bits, w.partial, overwrite);
       return check_launch("hashgrid backward (binned)");
     } else {
       return fail(MRI_ERR_UNSUPPORTED, "binned backward supports dim <= 4, n_features <= 4");
@@ -642,7 +658,7 @@ extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* gr
 namespace {
 int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
                   int64_t sl, int64_t sr, int64_t sf, float* d_table, int32_t method, int phase,
-                  void* workspace, int64_t workspace_bytes_given, void* stream) {
+                  int overwrite, void* workspace, int64_t workspace_bytes_given, void* stream) {
   if (int rc = validate(grid)) return rc;
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
@@ -668,13 +684,19 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
     bool any_split = false;
     for (int e = 0; e < plan.n_entries; ++e) any_split |= plan.ws_offset[e] >= 0;
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, dense_blocks, w,
-                                    grid->n_levels, acc_blocks, any_split, phase, x, d_out, n, sl,
-                                    sr, sf, d_table, (hipStream_t)stream);
+                                    grid->n_levels, acc_blocks, any_split, phase, overwrite, x,
+                                    d_out, n, sl, sr, sf, d_table, (hipStream_t)stream);
     if (rc) return rc;
   }
-  if (atomic_mask && phase != 1)
+  if (atomic_mask && phase != 1) {
+    if (overwrite)  // the atomic kernel can only add: clear its levels first
+      for (int l = 0; l < grid->n_levels; ++l)
+        if ((atomic_mask >> l) & 1u)
+          (void)hipMemsetAsync(d_table + grid->table_offset[l] * F, 0,
+                               (size_t)grid->table_size[l] * F * 4, (hipStream_t)stream);
     return launch_backward_atomic(grid, atomic_mask, x, d_out, n, sl, sr, sf, d_table,
                                   (hipStream_t)stream);
+  }
   return MRI_OK;
 }
 }  // namespace
@@ -682,7 +704,7 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
 extern "C" int mri_hashgrid_backward_prepare(const mri_grid_desc* grid, const float* x, int64_t n,
                                              int32_t method, void* workspace,
                                              int64_t workspace_bytes, void* stream) {
-  return backward_impl(grid, x, nullptr, n, 0, 0, 0, nullptr, method, 1, workspace,
+  return backward_impl(grid, x, nullptr, n, 0, 0, 0, nullptr, method, 1, 0, workspace,
                        workspace_bytes, stream);
 }
 
@@ -692,7 +714,8 @@ extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
                                      float* d_table, int32_t method, void* workspace,
                                      int64_t workspace_bytes_given, void* stream) {
   const int phase = (method & MRI_BWD_PREPARED) ? 2 : 0;
+  const int overwrite = (method & MRI_BWD_OVERWRITE) ? 1 : 0;
   return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
-                       d_table, method & ~MRI_BWD_PREPARED, phase, workspace,
-                       workspace_bytes_given, stream);
+                       d_table, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, overwrite,
+                       workspace, workspace_bytes_given, stream);
 }

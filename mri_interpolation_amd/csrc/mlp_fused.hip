@@ -668,6 +668,7 @@ struct ReduceArgs {
   const float* partial;
   int slabs, slab;
   int n_seg;
+  int overwrite;
   int seg_begin[8];   // offsets inside a slab
   int seg_len[8];
   float* dst[8];
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const ReduceArgs r) {
 #pragma unroll
   for (int g = 0; g < 8; ++g)
     if (g < r.n_seg && e >= r.seg_begin[g] && e < r.seg_begin[g] + r.seg_len[g])
-      r.dst[g][e - r.seg_begin[g]] += s;
+      r.dst[g][e - r.seg_begin[g]] = r.overwrite ? s : r.dst[g][e - r.seg_begin[g]] + s;
 }
 
 template <int H, int KP>
@@ -772,7 +773,7 @@ extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int
   return dispatch(a, hidden, false, pick_blocks(hidden, n), (hipStream_t)stream);
 }
 
-extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n, int32_t k_in,
+static int tiny_mlp_train_impl(int overwrite, const float* x, const float* target, int64_t n, int32_t k_in,
                                   int32_t hidden, const float* w1, const float* b1,
                                   const float* w2, const float* b2, const float* w3,
                                   const float* b3, float grad_divisor, float* d_w1, float* d_b1,
@@ -800,7 +801,7 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
   a.inv_n = (float)(1.0 / (double)n);
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
-  r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7;
+  r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7, r.overwrite = overwrite;
   const int lens[7] = {hidden * k_in, hidden, hidden * hidden, hidden, hidden, 1, 1};
   float* dsts[7] = {d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, loss_out};
   int off = 0;
@@ -811,4 +812,29 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 64)), dim3(256), 0,
                      (hipStream_t)stream, r);
   return check_launch("slab_reduce_kernel");
+}
+
+extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n, int32_t k_in,
+                                  int32_t hidden, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, const float* w3,
+                                  const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                  float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                  float* loss_out, float* y, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  return tiny_mlp_train_impl(0, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
+                             d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
+                             workspace_bytes, stream);
+}
+
+extern "C" int mri_tiny_mlp_train_overwrite(const float* x, const float* target, int64_t n,
+                                            int32_t k_in, int32_t hidden, const float* w1,
+                                            const float* b1, const float* w2, const float* b2,
+                                            const float* w3, const float* b3, float grad_divisor,
+                                            float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                            float* d_w3, float* d_b3, float* d_x, float* loss_out,
+                                            float* y, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
+  return tiny_mlp_train_impl(1, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
+                             d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
+                             workspace_bytes, stream);
 }

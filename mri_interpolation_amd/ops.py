@@ -117,8 +117,8 @@ def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, 
 
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                       d_table: torch.Tensor, feature_major: bool = False, method: int = 0,
-                      prepared: bool = False):
-    """d_table += scatter of d_out (accumulates)."""
+                      prepared: bool = False, overwrite: bool = False):
+    """d_table += scatter of d_out (or d_table = ..., with overwrite=True)."""
     _gpu(x, d_out, d_table)
     x = _rowmajor(x).contiguous()
     n = x.shape[0]
@@ -126,7 +126,8 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
         d_out = d_out.contiguous()
     sl, sr, sf = _enc_strides(desc, n, feature_major)
     ws = backward_workspace(desc, n, x.device) if method != 1 else None
-    flags = method | (_lib.BWD_PREPARED if prepared else 0)
+    flags = (method | (_lib.BWD_PREPARED if prepared else 0)
+             | (_lib.BWD_OVERWRITE if overwrite else 0))
     _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
               _ptr(d_table), flags, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
               _stream())
@@ -296,14 +297,16 @@ def tiny_mlp_forward(x_fm, params, y=None):
 
 
 def tiny_mlp_train(x_fm, target, params, grads, loss_out, d_x=None, y=None,
-                   grad_divisor: float = 1.0):
-    """Forward + MSE + backward of the tiny MLP in one kernel; grads accumulate."""
+                   grad_divisor: float = 1.0, overwrite: bool = False):
+    """Forward + MSE + backward of the tiny MLP in one kernel; grads accumulate (or are
+    overwritten, together with loss_out, when overwrite=True)."""
     (w1, b1), (w2, b2), (w3, b3) = params
     (g1, gb1), (g2, gb2), (g3, gb3) = grads
     _gpu(x_fm, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_x, y)
     k_in, n = x_fm.shape
     ws = _tiny_workspace(k_in, w1.shape[0], n, x_fm.device)
-    _lib.call("mri_tiny_mlp_train", _ptr(x_fm), _ptr(target), n, k_in, w1.shape[0], _ptr(w1),
+    _lib.call("mri_tiny_mlp_train_overwrite" if overwrite else "mri_tiny_mlp_train", _ptr(x_fm),
+              _ptr(target), n, k_in, w1.shape[0], _ptr(w1),
               _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor), _ptr(g1),
               _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3), _ptr(d_x), _ptr(loss_out),
               _ptr(y), _ptr(ws), ws.numel() * 4, _stream())

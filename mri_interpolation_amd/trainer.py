@@ -190,21 +190,22 @@ class FusedStep:
         self._bucket_cache = (key, out)
         return out
 
-    def _hash_backward(self, coords, d_enc):
+    def _hash_backward(self, coords, d_enc, overwrite=False):
         """Table gradient; with several ranks, reduce each finished level group right away."""
         enc, n = self.encoder, coords.shape[0]
         if self.grad_buckets <= 1:
             if self._counted:
                 torch.cuda.current_stream().wait_stream(self._side)
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
-                                  method=self.bwd_method, prepared=self._counted)
+                                  method=self.bwd_method, prepared=self._counted,
+                                  overwrite=overwrite)
             self._counted = False
             return []
         pending = []
         rows_per_level = enc.n_features_per_level
         for desc, first, grad_slice in self._level_buckets(n):
             ops.hashgrid_backward(desc, coords, d_enc[first * rows_per_level:], self._table_grad,
-                                  feature_major=True, method=self.bwd_method)
+                                  feature_major=True, method=self.bwd_method, overwrite=overwrite)
             pending.append(parallel.all_reduce_async(grad_slice))
         return pending
 
@@ -218,16 +219,19 @@ class FusedStep:
 
     def backward(self, coords, target, ws):
         """Gradients of mean squared error into the flat gradient buffer (zeroed here)."""
+        if self.use_tiny:
+            # every gradient (tables, decoder) and the loss are OVERWRITTEN by the two kernels
+            # below: no zeroing pass over the flat gradient buffer
+            with self._phase("mlp_fused"):
+                ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"], self.tiny["grads"],
+                                   self.loss, d_x=ws["d_enc"], grad_divisor=float(self.world),
+                                   overwrite=True)
+            with self._phase("hashgrid_bwd"):
+                self._pending = self._hash_backward(coords, ws["d_enc"], overwrite=True)
+            return
         with self._phase("zero_grad"):
             self.flat.grad.zero_()
             self.loss.zero_()
-        if self.use_tiny:
-            with self._phase("mlp_fused"):
-                ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"], self.tiny["grads"],
-                                   self.loss, d_x=ws["d_enc"], grad_divisor=float(self.world))
-            with self._phase("hashgrid_bwd"):
-                self._pending = self._hash_backward(coords, ws["d_enc"])
-            return
         last = len(self.layers) - 1
         pred = ws["y"][last]
         dz = ws["dz"][last]

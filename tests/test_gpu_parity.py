@@ -531,6 +531,12 @@ def test_bucketed_backward_equals_single_launch(amd):
     _, ws = step.forward(x, train=True)
     step.backward(x, y, ws)
     want = step.flat.grad.clone()
+    # the fused chain overwrites every gradient: stale contents of the buffer do not matter
+    live = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    step.flat.grad.fill_(3.0)
+    step.backward(x, y, ws)
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in net.parameters()]), live)
+    step.flat.grad.copy_(want)
     # bucketed path; no process group -> the reductions are no-ops.  world = 2 pre-divides the
     # gradients by two in the loss, which is exact in binary floating point.
     step.world, step.grad_buckets = 2, 4
