@@ -255,29 +255,35 @@ __global__ __launch_bounds__(64) void bin_chunk_scan_kernel(const uint32_t* __re
 
 // ------------------------------------------------------------------------------ 3. prefix
 // Bin counts (in `cursor`) -> exclusive offsets; `cursor` then holds each bin's write cursor.
-__global__ __launch_bounds__(1024) void bin_prefix_kernel(uint32_t* __restrict__ cursor,
-                                                          uint32_t* __restrict__ offsets,
-                                                          uint32_t* __restrict__ counts,
-                                                          int total_bins) {
-  __shared__ uint32_t chunk_sum[1024];
-  __shared__ uint32_t chunk_off[1025];
-  const int per = (total_bins + 1023) / 1024;
+// One 256-thread workgroup and 32 bytes of LDS: this kernel is queued on the side stream and must
+// find room beside the decoder kernel, whose workgroups hold all but 2.5 KiB of every CU's LDS.
+__global__ __launch_bounds__(256) void bin_prefix_kernel(uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ offsets,
+                                                         uint32_t* __restrict__ counts,
+                                                         int total_bins) {
+  __shared__ uint32_t wave_total[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (total_bins + 255) / 256;
   const int lo = threadIdx.x * per, hi = min(total_bins, lo + per);
   uint32_t s = 0;
   for (int b = lo; b < hi; ++b) s += (cursor[b] + 3u) & ~3u;  // bins start on 16-byte boundaries
-  chunk_sum[threadIdx.x] = s;
+  uint32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_total[wave] = incl;
   __syncthreads();
-  if (threadIdx.x < 64) wave_exclusive_scan<16>(chunk_sum, chunk_off, 1024);
-  __syncthreads();
-  uint32_t run = chunk_off[threadIdx.x];
+  uint32_t run = incl - s;
+  for (int w = 0; w < wave; ++w) run += wave_total[w];
   for (int b = lo; b < hi; ++b) {
     const uint32_t v = cursor[b];
     offsets[b] = run;
     counts[b] = v;
-    cursor[b] = run;
     run += (v + 3u) & ~3u;
   }
-  if (threadIdx.x == 0) offsets[total_bins] = chunk_off[1024];
+  if (threadIdx.x == 255) offsets[total_bins] = run;
 }
 
 // ------------------------------------------------------------------------------ 5. accumulate
@@ -619,7 +625,7 @@ struct BinnedLaunch {
                            w.rec_slot, w.rec_val, w.records, w.max_bits);
         hipLaunchKernelGGL(bin_chunk_scan_kernel, dim3((unsigned)plan.total_bins), dim3(64), 0, st,
                            w.chunk_hist, w.chunk_base, w.cursor, chunks);
-        hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(1024), 0, st, w.cursor, w.offsets,
+        hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(256), 0, st, w.cursor, w.offsets,
                            w.counts, plan.total_bins);
       }
       if (phase == 1) return check_launch("hashgrid backward (count)");
