@@ -250,26 +250,44 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
       const float* row = cur + threadIdx.x * p_so;
       for (int c = 0; c < kc; ++c) rowsum += row[c * p_sc];
     }
-    auto mfma_steps = [&](const int k_lo, const int k_hi) {
+    // Fragment reads software-pipelined in groups of U contraction pairs (the reads of group
+    // g+1 are issued before the MFMAs of group g): bounded register use -- a fully unrolled
+    // chunk lets the compiler hoist all 64 fragment reads and spill.
+    constexpr int U = 4;
+    auto fetch = [&](float (&pa)[U][TI], float (&qb)[U][TJ], int kk0) {
 #pragma unroll
-      for (int kk = k_lo; kk < k_hi; kk += 2) {
-        float pa[TI], qb[TJ];
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) pa[ti] = pf[ti * 32 * p_so + kk * p_sc];
+        for (int ti = 0; ti < TI; ++ti) pa[u][ti] = pf[ti * 32 * p_so + (kk0 + 2 * u) * p_sc];
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) qb[tj] = qf[tj * 32 * q_so + kk * q_sc];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < TJ; ++tj)
-            acc[ti][tj] =
-                __builtin_amdgcn_mfma_f32_32x32x2f32(pa[ti], qb[tj], acc[ti][tj], 0, 0, 0);
+        for (int tj = 0; tj < TJ; ++tj) qb[u][tj] = qf[tj * 32 * q_so + (kk0 + 2 * u) * q_sc];
       }
     };
-    if (kc == KB) {
-      mfma_steps(0, KB);
-    } else {  // ragged tail of the contraction (zero-filled by load_tile): stop at the last pair
-      for (int kk = 0; kk < kc; kk += 2) mfma_steps(kk, kk + 2);
+    auto compute = [&](const float (&pa)[U][TI], const float (&qb)[U][TJ], int n_steps) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (u < n_steps) {
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+              acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[u][ti], qb[u][tj],
+                                                                 acc[ti][tj], 0, 0, 0);
+        }
+    };
+    {
+      // kc <= KB = 32 -> at most 16 pairs = 4 groups; reads beyond kc stay inside the (zero
+      // filled) stage, their products are skipped
+      const int pairs = (kc + 1) / 2;
+      float pa0[U][TI], qb0[U][TJ], pa1[U][TI], qb1[U][TJ];
+      fetch(pa0, qb0, 0);
+      fetch(pa1, qb1, 2 * U);
+      compute(pa0, qb0, pairs);
+      fetch(pa0, qb0, 4 * U);
+      compute(pa1, qb1, pairs - U);
+      fetch(pa1, qb1, 6 * U);
+      compute(pa0, qb0, pairs - 2 * U);
+      compute(pa1, qb1, pairs - 3 * U);
     }
     if (more) {
       store_tile<BI>(nxt, pr, a.p.mode);
