@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=500,
                     help="total training steps before the PSNR evaluation (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-every", type=int, default=8,
+                    help="bracket the phases with HIP events on every n-th timed step only: "
+                         "an event pair stalls the queue ~15 us, 5 pairs per step cost 8 %%")
     ap.add_argument("--bwd-method", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[],
                     help="library tuning option name=value (mri_set_option), repeatable")
@@ -153,10 +156,15 @@ def main():
     per_epoch = (hi - lo) // w["batch"]
     counter = [0]
 
+    events = {}
+    sampling = [False]
+
     def one_step():
         k = counter[0]
         counter[0] += 1
         loader.set_epoch(k // per_epoch)
+        step.phase_events = events if sampling[0] and (k - args.warmup) % max(1, args.phase_every) == 0 \
+            else None
         with step._phase("coord_gen"):
             idx = loader.indices((k % per_epoch) * w["batch"], w["batch"])
             ds.batch(idx, coords, target)
@@ -164,7 +172,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    step.phase_events = {}
+    sampling[0] = True
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -173,8 +181,9 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+    step.phase_events = events
     phases = step.phase_ms()
-    step.phase_events = None
+    step.phase_events, sampling[0] = None, False
 
     # PSNR vs ground-truth voxels at a fixed step count (outside the timed region)
     psnr = None
@@ -219,6 +228,7 @@ def main():
                    "parallelism": f"dp{world} z-slab" if world > 1 else "single GPU"},
         "roofline": roof,
         "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
+        "phases_sampled_every": max(1, args.phase_every),
         "final_loss": float(loss),
     }
     if step.encoder is not None:  # whole-step HBM fraction as north_star defines it

@@ -153,6 +153,16 @@ int mri_linear_backward_weight(const float* dy, int64_t lddy, const float* x,
 int mri_apply_deriv(float* dy, int64_t lddy, int32_t deriv_mode, const float* deriv,
                     int64_t ldd, int64_t m, int32_t n, void* stream);
 
+/* ---- frequency encoding ----------------------------------------------------------------------
+ * `Frequency.forward` (reference encoding.py:43-66): for every row and input axis d,
+ * out[d*2L + l] = sin(x_d * 2^l), out[d*2L + L + l] = cos(x_d * 2^l), l = 0..L-1.
+ *   x (n, dim) row-major with leading dimension ldx; out (n, dim*2L) with leading dimension ldo.
+ * mri_frequency_backward writes (does not accumulate) dx (n, dim) from d_out (n, dim*2L). */
+int mri_frequency_forward(const float* x, int64_t ldx, int64_t n, int32_t dim, int32_t n_levels,
+                          float* out, int64_t ldo, void* stream);
+int mri_frequency_backward(const float* x, int64_t ldx, const float* d_out, int64_t ldg, int64_t n,
+                           int32_t dim, int32_t n_levels, float* dx, int64_t lddx, void* stream);
+
 /* ---- fused tiny MLP ------------------------------------------------------------------------
  * The decoder of BASELINE configs 2/4/5: k_in -> hidden -> hidden -> 1, ReLU on the hidden
  * layers, linear output (reference config/hash_config.json "network"; module form

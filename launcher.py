@@ -117,7 +117,7 @@ def main(argv=None):
             and len(config.base_resolution) != config.dim_in:
         raise SystemExit(f"base_resolution {config.base_resolution} does not match the "
                          f"{config.dim_in}-D volume (SURVEY.md Q7): pass --slice or --tiny_mlp")
-    config.norm_siren = config.model_class == "SirenNet"
+    config.norm_siren = config.model_class in ("SirenNet", "ModulatedSirenNet")
 
     model = build_model(config, models).cuda()
     datamodule = datamodules.MriDataModule(config=config, volume=volume,

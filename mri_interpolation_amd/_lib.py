@@ -49,6 +49,8 @@ SIGNATURES = {
                                  _P],
     "mri_linear_backward_weight": [_P, _I64, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P],
     "mri_apply_deriv": [_P, _I64, _I32, _P, _I64, _I64, _I32, _P],
+    "mri_frequency_forward": [_P, _I64, _I64, _I32, _I32, _P, _I64, _P],
+    "mri_frequency_backward": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     "mri_mse_loss": [_P, _P, _I64, _F, _P, _P, _P],
     "mri_tiny_mlp_forward": [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "mri_tiny_mlp_train": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,

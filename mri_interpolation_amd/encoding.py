@@ -174,3 +174,22 @@ class MultiResHashGridV2(_HashGridBase):
             finest_resolution = (finest_resolution,) * dim
         super().__init__(dim, n_levels, n_features_per_level, log2_hashmap_size,
                          tuple(base_resolution), tuple(finest_resolution), isotropic=False)
+
+
+class Frequency(nn.Module):
+    """NeRF positional encoding (reference encoding.py:43-66): per input axis
+    [sin(2^0 x) .. sin(2^(L-1) x), cos(2^0 x) .. cos(2^(L-1) x)], one HIP kernel
+    (csrc/frequency.hip) forward and one backward."""
+
+    def __init__(self, dim: int, n_levels: int = 10):
+        super().__init__()
+        self.n_levels = n_levels
+        assert self.n_levels > 0
+        freqs = 2.0 ** torch.linspace(0.0, n_levels - 1, n_levels)
+        self.register_buffer("freqs", freqs, persistent=False)
+        self.input_dim = dim
+        self.output_dim = dim * n_levels * 2
+
+    def forward(self, x: torch.Tensor):
+        return ops.FrequencyFunction.apply(x, self.n_levels)
+

@@ -1,7 +1,7 @@
 """Coordinate networks with the reference's class surface, computed by the gfx950 kernels.
 
 Mirrors reference `models.py`: `BaseMLP` (models.py:20-95), `Sine` (:108-114), `SirenLayer`
-(:117-156), `SirenNet` (:160-233), `HashMLP` (:658-754): same constructor arguments,
+(:117-156), `SirenNet` (:160-233), `Modulator` / `ModulatedSirenNet` (:236-322), `HashMLP` (:658-754): same constructor arguments,
 `forward(x)`, `training_step`, `predict_step`, `configure_optimizers`, same state-dict keys.
 Known defects of the reference are resolved to the INTENDED semantics:
   Q1  HashMLP.forward applies the decoder blocks in sequence (the reference calls a ModuleList);
@@ -216,6 +216,67 @@ class SirenNet(BaseMLP):
         for layer in self.layers:
             x = layer(x)
         return self.last_layer(x)
+
+
+def cast_tuple(val, repeat=1):
+    return val if isinstance(val, tuple) else ((val,) * repeat)
+
+
+class Modulator(nn.Module):
+    """ReLU modulator of 'Modulated periodic activations' (reference models.py:236-260): layer
+    i sees cat(hidden_{i-1}, z); returns every hidden state.  Each Linear+ReLU is one fused
+    kernel; state-dict keys `layers.{i}.0.weight/bias` as in the reference."""
+
+    def __init__(self, dim_in, dim_hidden, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for ind in range(n_layers):
+            dim = dim_in if ind == 0 else (dim_hidden + dim_in)
+            self.layers.append(nn.Sequential(
+                FusedLinear(dim, dim_hidden, activation=ops.ACT_RELU), _Fused("ReLU")))
+
+    def forward(self, z):
+        x = z
+        hiddens = []
+        for layer in self.layers:
+            x = layer(x)
+            hiddens.append(x)
+            x = torch.cat((x, z), dim=1)
+        return tuple(hiddens)
+
+
+class ModulatedSirenNet(SirenNet):
+    """SIREN whose hidden layers are multiplied elementwise by a modulator's hidden states
+    (reference models.py:263-322).  Like the reference, the class also carries the default
+    SirenNet stack its base constructor builds (`layers.*`, `last_layer.*`: unused by
+    forward, present in the state dict)."""
+
+    def __init__(self, dim_in: int = 3, dim_hidden: int = 64, dim_out: int = 1,
+                 n_layers: int = 4, w0: float = 30.0, w0_initial: float = 30.0,
+                 sigma: float = 6.0, use_bias: bool = True, final_activation=None,
+                 lr: float = 1e-4):
+        super().__init__()
+        self.dim_in = dim_in
+        self.dim_hidden = dim_hidden
+        self.dim_out = dim_out
+        self.n_layers = n_layers
+        self.w0 = w0
+        self.w0_initial = w0_initial
+        self.sigma = sigma
+        self.use_bias = use_bias
+        self.final_activation = final_activation
+        self.lr = lr
+        self.losses = []
+        self.modulator = Modulator(dim_in=dim_in, dim_hidden=dim_hidden, n_layers=n_layers)
+        self.siren = SirenNet(dim_in=dim_in, dim_hidden=dim_hidden, dim_out=dim_out,
+                              n_layers=n_layers, w0=w0, w0_initial=w0_initial, sigma=sigma,
+                              use_bias=use_bias, final_activation=final_activation, lr=lr)
+
+    def forward(self, x):
+        mods = cast_tuple(self.modulator(x), self.n_layers)
+        for layer, mod in zip(self.siren.layers, mods):
+            x = ops.modulate(layer(x), mod)
+        return self.siren.last_layer(x)
 
 
 class HashMLP(BaseMLP):

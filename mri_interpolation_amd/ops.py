@@ -267,6 +267,66 @@ def linear_act(x, weight, bias, activation=ACT_IDENTITY, w0=1.0):
     return LinearActFunction.apply(x, weight, bias, activation, w0)
 
 
+class ModulateFunction(torch.autograd.Function):
+    """y = x (.) m, the elementwise modulation of reference models.py:318-320 (`x *= mod`)."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        x2, m2 = _rowmajor(x), _rowmajor(m)
+        ctx.save_for_backward(x2, m2)
+        return apply_deriv(x2.clone(), DERIV_MUL, m2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, m2 = ctx.saved_tensors
+        dy = _rowmajor(dy)
+        dx = apply_deriv(dy.clone(), DERIV_MUL, m2) if ctx.needs_input_grad[0] else None
+        dm = apply_deriv(dy.clone(), DERIV_MUL, x2) if ctx.needs_input_grad[1] else None
+        return dx, dm
+
+
+def modulate(x, m):
+    return ModulateFunction.apply(x, m)
+
+
+# --------------------------------------------------------------------------- frequency encoding
+def frequency_forward(x, n_levels: int, out=None):
+    _gpu(x, out)
+    x = _rowmajor(x)
+    n, dim = x.shape
+    if out is None:
+        out = torch.empty((n, dim * 2 * n_levels), device=x.device, dtype=torch.float32)
+    _lib.call("mri_frequency_forward", _ptr(x), x.stride(0), n, dim, n_levels, _ptr(out),
+              out.stride(0), _stream())
+    return out
+
+
+def frequency_backward(x, d_out, n_levels: int):
+    _gpu(x, d_out)
+    x, d_out = _rowmajor(x), _rowmajor(d_out)
+    n, dim = x.shape
+    dx = torch.empty((n, dim), device=x.device, dtype=torch.float32)
+    _lib.call("mri_frequency_backward", _ptr(x), x.stride(0), _ptr(d_out), d_out.stride(0), n,
+              dim, n_levels, _ptr(dx), dx.stride(0), _stream())
+    return dx
+
+
+class FrequencyFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_levels):
+        lead = x.shape[:-1]
+        x2 = _rowmajor(x.reshape(-1, x.shape[-1]))
+        ctx.save_for_backward(x2)
+        ctx.n_levels, ctx.shape = n_levels, x.shape
+        return frequency_forward(x2, n_levels).reshape(*lead, -1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x2,) = ctx.saved_tensors
+        dx = frequency_backward(x2, d_out.reshape(x2.shape[0], -1), ctx.n_levels)
+        return dx.reshape(ctx.shape), None
+
+
 # --------------------------------------------------------------------------- fused tiny MLP
 def tiny_mlp_supported(k_in: int, hidden: int, dim_out: int) -> bool:
     return bool(_lib.load().mri_tiny_mlp_supported(k_in, hidden, dim_out))

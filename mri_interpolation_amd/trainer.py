@@ -30,6 +30,8 @@ class _Layer:
 def fusable_layers(model) -> Optional[tuple]:
     """(encoder or None, [_Layer, ...]) if the model is a plain chain of fused layers."""
     enc, layers = None, []
+    if isinstance(model, models.ModulatedSirenNet):
+        return None  # two interleaved stacks: runs training_step + autograd over the HIP ops
     if isinstance(model, models.SirenNet):
         for l in list(model.layers) + [model.last_layer]:
             if l._code is None:

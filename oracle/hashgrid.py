@@ -173,3 +173,11 @@ def encode_loops(x: np.ndarray, tables: Sequence[np.ndarray],
                 acc = acc + table[h % size] * w
             out[i, l * feats:(l + 1) * feats] = acc
     return out
+
+
+def frequency_encode(x: torch.Tensor, n_levels: int) -> torch.Tensor:
+    """encoding.py:43-66 (`Frequency`): per input axis, [sin(2^0 x) .. sin(2^(L-1) x),
+    cos(2^0 x) .. cos(2^(L-1) x)]; output (..., dim * 2L), axis-major."""
+    freqs = 2.0 ** torch.linspace(0.0, n_levels - 1, n_levels)
+    v = x.unsqueeze(-1) * freqs
+    return torch.cat((torch.sin(v), torch.cos(v)), dim=-1).flatten(-2, -1)

@@ -4,6 +4,7 @@ Follows reference `models.py`:
   BaseMLP layer stack + training contract   models.py:46-74
   Sine / SirenLayer (init + forward)        models.py:108-156
   SirenNet.forward                          models.py:199-233
+  Modulator / ModulatedSirenNet.forward     models.py:236-260, 311-322
   HashMLP decoder blocks (as intended, Q1)  models.py:712-744
 Adam restates torch.optim.Adam (single-tensor, default betas/eps, no weight
 decay, no amsgrad) which `configure_optimizers` builds at models.py:68-70.
@@ -63,6 +64,45 @@ def siren_forward(x: torch.Tensor, params: Params, w0: float = 30.0,
         x = torch.sin((w0_initial if i == 0 else w0) * F.linear(x, w, b))
     w, b = params[-1]
     return F.linear(x, w, b)
+
+
+def modulator_forward(z: torch.Tensor, params: Params) -> List[torch.Tensor]:
+    """models.py:251-260: hidden_i = relu(Linear_i(x)); the next layer sees
+    cat(hidden_i, z) (hidden first, latent second)."""
+    x, hiddens = z, []
+    for w, b in params:
+        x = torch.relu(F.linear(x, w, b))
+        hiddens.append(x)
+        x = torch.cat((x, z), dim=1)
+    return hiddens
+
+
+def modulated_siren_forward(x: torch.Tensor, siren: Params, modulator: Params, w0: float = 30.0,
+                            w0_initial: float = 30.0) -> torch.Tensor:
+    """models.py:311-322: every hidden SirenLayer output is multiplied elementwise by the
+    modulator's hidden state of the same depth (computed from the same coordinates), then
+    the linear last layer."""
+    mods = modulator_forward(x, modulator)
+    n_hidden = len(siren) - 1
+    for i, (w, b) in enumerate(siren[:n_hidden]):
+        x = torch.sin((w0_initial if i == 0 else w0) * F.linear(x, w, b)) * mods[i]
+    w, b = siren[-1]
+    return F.linear(x, w, b)
+
+
+def modulator_init(dim_in: int, dim_hidden: int, n_layers: int, seed: int) -> Params:
+    """nn.Linear default ranges for models.py:245-249 (input widths dim_in, then
+    dim_hidden + dim_in); values from oracle.detrand."""
+    from . import detrand
+    out: Params = []
+    for i in range(n_layers):
+        fan_in = dim_in if i == 0 else dim_hidden + dim_in
+        bound = 1.0 / math.sqrt(fan_in)
+        w = detrand.uniform(dim_hidden * fan_in, seed * 100 + 2 * i, -bound, bound)
+        b = detrand.uniform(dim_hidden, seed * 100 + 2 * i + 1, -bound, bound)
+        out.append((torch.from_numpy(w.reshape(dim_hidden, fan_in).copy()),
+                    torch.from_numpy(b.copy())))
+    return out
 
 
 def relu_mlp_forward(x: torch.Tensor, params: Params, final_activation: bool) -> torch.Tensor:

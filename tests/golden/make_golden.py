@@ -127,10 +127,59 @@ def encoder_fixture(name, enc, ctor, dim, n_rand, seed, scale):
          **arrays)
 
 
+def extra_models(encoding, models):
+    """O9 / O10: SURVEY.md section 8(f) rank 4 -- ModulatedSirenNet (models.py:236-322) and
+    the NeRF frequency encoding (encoding.py:43-66)."""
+    for name, dim_in, hidden, n_layers, n, seed in [("modsiren_2d", 2, 64, 3, 192, 61),
+                                                    ("modsiren_3d", 3, 128, 4, 160, 62)]:
+        net = models.ModulatedSirenNet(dim_in=dim_in, dim_hidden=hidden, dim_out=1,
+                                       n_layers=n_layers)
+        sparams = omlp.siren_init(dim_in, hidden, 1, n_layers, seed)
+        mparams = omlp.modulator_init(dim_in, hidden, n_layers, seed + 500)
+        with torch.no_grad():
+            for layer, (w, b) in zip(list(net.siren.layers) + [net.siren.last_layer], sparams):
+                layer.weight.copy_(w)
+                layer.bias.copy_(b)
+            for seq, (w, b) in zip(net.modulator.layers, mparams):
+                seq[0].weight.copy_(w)
+                seq[0].bias.copy_(b)
+        x = detrand.uniform(n * dim_in, seed + 1, -1.0, 1.0).reshape(n, dim_in)
+        y = detrand.uniform(n, seed + 2, -1.0, 1.0).reshape(n, 1)
+        xt = torch.from_numpy(x)
+        pred = net(xt.clone())  # the reference multiplies in place
+        loss = torch.nn.functional.mse_loss(torch.from_numpy(y), pred)
+        loss.backward()
+        arrays = dict(x=x, y=y, pred=pred.detach().numpy(), loss=np.float32(loss.item()))
+        for i, layer in enumerate(list(net.siren.layers) + [net.siren.last_layer]):
+            arrays[f"siren_gw_{i}"] = layer.weight.grad.numpy().copy()
+            arrays[f"siren_gb_{i}"] = layer.bias.grad.numpy().copy()
+        for i, seq in enumerate(net.modulator.layers):
+            arrays[f"mod_gw_{i}"] = seq[0].weight.grad.numpy().copy()
+            arrays[f"mod_gb_{i}"] = seq[0].bias.grad.numpy().copy()
+        save(name, dict(dim_in=dim_in, dim_hidden=hidden, n_layers=n_layers, seed=seed,
+                        w0=30.0, w0_initial=30.0,
+                        state_dict_keys=sorted(net.state_dict().keys())), **arrays)
+
+    arrays = {}
+    for dim, n_levels in [(2, 10), (3, 6), (4, 4)]:
+        enc = encoding.Frequency(dim, n_levels=n_levels)
+        x = detrand.uniform(200 * dim, 70 + dim, -1.0, 1.0).reshape(200, dim)
+        x[:4] = [[0.0] * dim, [1.0] * dim, [-1.0] * dim, [0.5] * dim]
+        xt = torch.from_numpy(x).requires_grad_(True)
+        out = enc(xt)
+        g = detrand.uniform(out.numel(), 80 + dim, -1.0, 1.0).reshape(out.shape)
+        out.backward(torch.from_numpy(g))
+        arrays.update({f"x_{dim}": x, f"out_{dim}": out.detach().numpy(), f"g_{dim}": g,
+                       f"dx_{dim}": xt.grad.numpy()})
+    save("frequency", dict(cases=[[2, 10], [3, 6], [4, 4]]), **arrays)
+
+
 def main():
     torch.manual_seed(1337)
     torch.set_num_threads(4)
     encoding, models = import_reference()
+    if "--extra-only" in sys.argv:  # leave the existing fixtures untouched
+        return extra_models(encoding, models)
 
     # ---- O1: hash ids (encoding.py:69-78) ------------------------------------------------
     arrays, cases = {}, []
@@ -324,6 +373,7 @@ def main():
     save("sample_slice_z3_t7", dict(shape=list(shape), scl_slope=slope, scl_inter=inter,
                                     slice="[:, :, 3, 7]"),
          raw_int16=np.ascontiguousarray(vol[:, :, 3, 7]))
+    extra_models(encoding, models)
 
 
 if __name__ == "__main__":

@@ -197,6 +197,59 @@ def load_siren(amd, fx):
     return net.cuda()
 
 
+@pytest.mark.parametrize("name", ["modsiren_2d", "modsiren_3d"])
+def test_modulated_siren_golden(amd, name):
+    """ModulatedSirenNet (reference models.py:236-322): forward, loss and every gradient."""
+    fx = load_golden(name)
+    m = fx.meta
+    net = amd.models.ModulatedSirenNet(dim_in=m["dim_in"], dim_hidden=m["dim_hidden"], dim_out=1,
+                                       n_layers=m["n_layers"])
+    assert sorted(net.state_dict().keys()) == m["state_dict_keys"]
+    siren = omlp.siren_init(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], m["seed"])
+    mod = omlp.modulator_init(m["dim_in"], m["dim_hidden"], m["n_layers"], m["seed"] + 500)
+    with torch.no_grad():
+        for layer, (w, b) in zip(list(net.siren.layers) + [net.siren.last_layer], siren):
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+        for seq, (w, b) in zip(net.modulator.layers, mod):
+            seq[0].weight.copy_(w)
+            seq[0].bias.copy_(b)
+    net = net.cuda()
+    x, y = cuda(fx["x"]), cuda(fx["y"])
+    loss = net.training_step((x, y), 0)
+    loss.backward()
+    assert_close(net(x).detach().cpu().numpy(), fx["pred"], REL_TOL, "pred")
+    assert abs(float(loss) - float(fx["loss"])) <= REL_TOL * abs(float(fx["loss"]))
+    for i, layer in enumerate(list(net.siren.layers) + [net.siren.last_layer]):
+        assert_close(layer.weight.grad.cpu().numpy(), fx[f"siren_gw_{i}"], REL_TOL, f"siren gw{i}")
+        assert_close(layer.bias.grad.cpu().numpy(), fx[f"siren_gb_{i}"], REL_TOL, f"siren gb{i}")
+    for i, seq in enumerate(net.modulator.layers):
+        assert_close(seq[0].weight.grad.cpu().numpy(), fx[f"mod_gw_{i}"], REL_TOL, f"mod gw{i}")
+        assert_close(seq[0].bias.grad.cpu().numpy(), fx[f"mod_gb_{i}"], REL_TOL, f"mod gb{i}")
+    # one optimiser step through the LightningModule protocol keeps everything finite
+    opt = net.configure_optimizers()
+    opt.step()
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_frequency_encoding_golden(amd):
+    """Frequency (reference encoding.py:43-66) forward and backward, plus empty input."""
+    fx = load_golden("frequency")
+    for dim, n_levels in fx.meta["cases"]:
+        enc = amd.encoding.Frequency(dim, n_levels=n_levels).cuda()
+        assert (enc.input_dim, enc.output_dim) == (dim, dim * 2 * n_levels)
+        x = cuda(fx[f"x_{dim}"]).requires_grad_(True)
+        out = enc(x)
+        assert_close(out.detach().cpu().numpy(), fx[f"out_{dim}"], 1e-6, f"out d{dim}")
+        out.backward(cuda(fx[f"g_{dim}"]))
+        assert_close(x.grad.cpu().numpy(), fx[f"dx_{dim}"], REL_TOL, f"dx d{dim}")
+        # leading batch axes are kept, like the reference's unsqueeze/flatten
+        out3 = enc(x.detach().reshape(4, -1, dim))
+        assert out3.shape == (4, x.shape[0] // 4, dim * 2 * n_levels)
+        assert torch.equal(out3.reshape(out.shape), out.detach())
+    assert enc(torch.empty(0, dim, device="cuda")).shape == (0, dim * 2 * n_levels)
+
+
 @pytest.mark.parametrize("name", ["siren_3d_5x256", "siren_2d_4x352", "siren_2d_3x64"])
 def test_siren_golden(amd, name):
     fx = load_golden(name)

@@ -151,6 +151,37 @@ def test_e2e_hash_adam():
             assert_close(b.numpy(), fx[f"b_{step}_{i}"], 1e-6, f"b{i} step {step}")
 
 
+@pytest.mark.parametrize("name", ["modsiren_2d", "modsiren_3d"])
+def test_modulated_siren(name):
+    fx = load_golden(name)
+    m = fx.meta
+    siren = omlp.siren_init(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], m["seed"])
+    mod = omlp.modulator_init(m["dim_in"], m["dim_hidden"], m["n_layers"], m["seed"] + 500)
+    for w, b in siren + mod:
+        w.requires_grad_(True)
+        b.requires_grad_(True)
+    pred = omlp.modulated_siren_forward(torch.from_numpy(fx["x"]), siren, mod)
+    loss = omlp.mse_loss(pred, torch.from_numpy(fx["y"]))
+    loss.backward()
+    assert_close(pred.detach().numpy(), fx["pred"], 1e-6, "pred")
+    assert abs(float(loss.detach()) - float(fx["loss"])) <= 1e-6 * abs(float(fx["loss"]))
+    for tag, params in (("siren", siren), ("mod", mod)):
+        for i, (w, b) in enumerate(params):
+            assert_close(w.grad.numpy(), fx[f"{tag}_gw_{i}"], 1e-6, f"{tag} gw{i}")
+            assert_close(b.grad.numpy(), fx[f"{tag}_gb_{i}"], 1e-6, f"{tag} gb{i}")
+
+
+def test_frequency_encoding():
+    fx = load_golden("frequency")
+    for dim, n_levels in fx.meta["cases"]:
+        x = torch.from_numpy(fx[f"x_{dim}"]).requires_grad_(True)
+        out = ohash.frequency_encode(x, n_levels)
+        assert out.shape == (x.shape[0], dim * 2 * n_levels)
+        np.testing.assert_array_equal(out.detach().numpy(), fx[f"out_{dim}"])
+        out.backward(torch.from_numpy(fx[f"g_{dim}"]))
+        assert_close(x.grad.numpy(), fx[f"dx_{dim}"], 1e-6, f"dx d{dim}")
+
+
 def test_e2e_siren_adam():
     fx = load_golden("e2e_siren_adam")
     m = fx.meta
