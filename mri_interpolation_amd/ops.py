@@ -318,7 +318,7 @@ class FrequencyFunction(torch.autograd.Function):
         x2 = _rowmajor(x.reshape(-1, x.shape[-1]))
         ctx.save_for_backward(x2)
         ctx.n_levels, ctx.shape = n_levels, x.shape
-        return frequency_forward(x2, n_levels).reshape(*lead, -1)
+        return frequency_forward(x2, n_levels).reshape(*lead, x.shape[-1] * 2 * n_levels)
 
     @staticmethod
     def backward(ctx, d_out):
