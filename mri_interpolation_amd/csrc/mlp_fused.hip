@@ -46,8 +46,30 @@ struct FusedArgs {
   int64_t n;
   int k_in;
   float grad_scale;    // 2 / (n * grad_divisor)
+  int stagger;         // team kernel: segments team 1 runs behind team 0
   float inv_n;
 };
+
+// Segment timing for tools/mlp_segments.py (a tools-only build with -DMRI_MLP_PROFILE; the
+// shipped library compiles these to nothing): shader-clock cycles per barrier-separated segment,
+// split into work (mark -> barrier entry) and wait (barrier entry -> exit), summed over tiles.
+#ifdef MRI_MLP_PROFILE
+__device__ long long* g_mlp_profile = nullptr;
+constexpr int kProfSlots = 32;
+#define PROF_BEGIN long long p_t = clock64(); long long p_acc[kProfSlots] = {};
+#define PROF_MARK(i) { const long long p_n = clock64(); p_acc[i] += p_n - p_t; p_t = p_n; }
+#define PROF_SYNC(i) { PROF_MARK(2 * (i)) __syncthreads(); PROF_MARK(2 * (i) + 1) }
+#define PROF_END(wave_in_wg)                                                              \
+  if (g_mlp_profile && (threadIdx.x & 63) == 0) {                                         \
+    long long* dst = g_mlp_profile + ((int64_t)blockIdx.x * 8 + (wave_in_wg)) * kProfSlots; \
+    for (int q = 0; q < kProfSlots; ++q) dst[q] = p_acc[q];                               \
+  }
+#else
+#define PROF_BEGIN
+#define PROF_MARK(i)
+#define PROF_SYNC(i) __syncthreads();
+#define PROF_END(w)
+#endif
 
 template <int H, int KP>
 struct Smem {
@@ -75,7 +97,7 @@ __device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __res
   // Software pipeline over groups of U contraction pairs: the LDS reads of group g+1 are
   // issued before the MFMAs of group g, so a wave that is alone on its matrix pipe does not
   // expose the ds_read latency once per group.  `steps` is a multiple of U at every call site.
-  constexpr int U = 4;
+  constexpr int U = TI * TJ >= 4 ? 2 : 4;  // >= 4 MFMAs (256 cycles) per group either way
   float av[2][U][TI], bv[2][U][TJ];
   auto fetch = [&](int buf, int s0) {
 #pragma unroll
@@ -96,13 +118,19 @@ __device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __res
           acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][ti], bv[buf][u][tj],
                                                              acc[ti][tj], 0, 0, 0);
   };
+  // sched_barrier: hipcc otherwise sinks a group's reads below the previous group's MFMAs
+  // (read, wait lgkmcnt(0), mfma, read, ... : one exposed LDS latency per pair)
   fetch(0, 0);
   int s = 0;
   for (; s + 2 * U <= steps; s += 2 * U) {
     fetch(1, s + U);
+    __builtin_amdgcn_sched_barrier(0);
     compute(0);
+    __builtin_amdgcn_sched_barrier(0);
     if (s + 2 * U < steps) fetch(0, s + 2 * U);
+    __builtin_amdgcn_sched_barrier(0);
     compute(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (s < steps) compute(0);  // steps = odd multiple of U
 }
@@ -121,7 +149,7 @@ __device__ __forceinline__ void zero(f32x16 (&acc)[TI][TJ]) {
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
 template <int H, int KP, bool TRAIN>
-__global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void tiny_mlp_kernel(const FusedArgs a) {
   using S = Smem<H, KP>;
   __shared__ S sm;
   constexpr int NB = H / 32;        // 32-wide blocks of the hidden width
@@ -186,8 +214,37 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
     }
   };
   const int64_t tiles = (a.n + kTile - 1) / kTile;
+  // the tile's targets are prefetched with x (a load issued where the loss needs it exposes its
+  // whole latency); dx of a tile is stored one tile late, right after the next tile's loads
+  // were issued, so the wait for x_next never has a fresh store in front of it
+  auto load_t = [&](int64_t m0) {
+    return (TRAIN && tid < kTile && m0 + tid < a.n) ? a.target[m0 + tid] : 0.f;
+  };
+  constexpr int DXT = (KP / 16) * (kTile / 16) / 4;  // 16 x 16 dx tiles per wave
+  f32x4 dx_pend[DXT];
+  int64_t dx_m0 = -1;
+  auto flush_dx = [&]() {
+    if (dx_m0 < 0) return;
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < DXT; ++u) {
+      const int tile = wave + 4 * u;
+      const int kb = tile / (kTile / 16), cb = tile % (kTile / 16);
+      const int64_t m = dx_m0 + cb * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kb * 16 + lq * 4 + r;
+        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[u][r];
+      }
+    }
+    dx_m0 = -1;
+  };
   float4 x_next[XV];
-  if ((int64_t)blockIdx.x < tiles) load_x((int64_t)blockIdx.x * kTile, x_next);
+  float t_next = 0.f;
+  if ((int64_t)blockIdx.x < tiles) {
+    load_x((int64_t)blockIdx.x * kTile, x_next);
+    t_next = load_t((int64_t)blockIdx.x * kTile);
+  }
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t m0 = t * kTile;
     __syncthreads();  // B0: previous tile is done with xs / h1 / h2
@@ -200,7 +257,12 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
       dst[0] = x_next[j].x, dst[S::ldx] = x_next[j].y, dst[2 * S::ldx] = x_next[j].z,
       dst[3 * S::ldx] = x_next[j].w;
     }
-    if (t + gridDim.x < tiles) load_x((t + gridDim.x) * kTile, x_next);
+    const float t_cur = t_next;
+    if (t + gridDim.x < tiles) {
+      load_x((t + gridDim.x) * kTile, x_next);
+      t_next = load_t((t + gridDim.x) * kTile);
+    }
+    if (TRAIN) flush_dx();
     __syncthreads();  // B1
 
     // ---- layer 1: h1 = relu(x W1^T + b1) -----------------------------------------------------
@@ -252,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
       if (m < a.n) {
         if (a.y) a.y[m] = y;
         if (TRAIN) {
-          const float diff = y - a.target[m];
+          const float diff = y - t_cur;
           loss += diff * diff;
           d = diff * a.grad_scale;
           g_b3 += d;
@@ -306,9 +368,10 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
                    sm.xs + (w1_kb * 32 + l31) + lh * S::ldx, 0, 2 * S::ldx, kTile / 2);
     // ---- dx^T = W1^T dz1^T (k_in x 64), 16x16 tiles so that all four waves take part ---------
     if (a.dx) {
-      constexpr int TILES = (KP / 16) * (kTile / 16);
       const int l15 = lane & 15, lq = lane >> 4;
-      for (int tile = wave; tile < TILES; tile += 4) {
+#pragma unroll
+      for (int u = 0; u < DXT; ++u) {
+        const int tile = wave + 4 * u;
         const int kb = tile / (kTile / 16), cb = tile % (kTile / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* pa = sm.w1 + lq * S::ldw1 + kb * 16 + l15;          // A(i = k, kk = o)
@@ -316,16 +379,13 @@ __global__ __launch_bounds__(kThreads) void tiny_mlp_kernel(const FusedArgs a) {
 #pragma unroll 8
         for (int s = 0; s < H / 4; ++s)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s * 4 * S::ldw1], pb[s * 4], acc, 0, 0, 0);
-        const int64_t m = m0 + cb * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = kb * 16 + lq * 4 + r;
-          if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = acc[r];
-        }
+        dx_pend[u] = acc;
       }
+      dx_m0 = m0;
     }
   }
   if (!TRAIN) return;
+  flush_dx();
 
   // ---- write this workgroup's partial gradients (plain stores, summed by reduce kernel) ----
   float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
@@ -426,9 +486,13 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   static_assert(H == 128 && KP == 32, "team kernel is laid out for 32 -> 128 -> 128 -> 1");
   using S = TeamSmem<H, KP>;
   __shared__ S sm;
-  const int team = threadIdx.x / kTeamThreads;
+  // wave-uniform indices live in SGPRs (readfirstlane), so the addresses built from them do not
+  // each take a vector register for the whole kernel
+  const int team = __builtin_amdgcn_readfirstlane(threadIdx.x / kTeamThreads);
   const int tid = threadIdx.x % kTeamThreads;        // thread within the team
-  const int lane = tid & 63, w = tid >> 6;           // wave within the team: owns block w
+  const int tid_outer = tid;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave within the team: owns block w
   const int l31 = lane & 31, lh = lane >> 5;
   typename S::Team& tm = sm.team[team];
 
@@ -456,6 +520,10 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   }
   const float b3 = a.b3[0];
 
+  // 512 threads leave 256 registers per lane.  Without this (empty) AGPR operand hipcc keeps all
+  // of them architectural, puts the 96 accumulator registers there too and spills addresses;
+  // with it the MFMA accumulators go to the 128 AccVGPRs and nothing spills.
+  asm volatile("" ::"a"(0.f));
   f32x16 g_w2[1][4];
   f32x16 g_w1[1][1];
   zero(g_w2);
@@ -463,7 +531,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   float g_b1 = 0.f, g_b2 = 0.f, g_w3 = 0.f, g_b3 = 0.f, loss = 0.f;
 
   // x tile of a team: 32 features x 32 coordinates = 256 float4 pieces, one per thread
-  auto load_x = [&](int64_t m0) {
+  auto load_x = [&](int64_t m0, int tid) {
     const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < a.k_in && m0 + c4 < a.n) {
@@ -483,27 +551,56 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   const int64_t tiles = (a.n + kTeamTile - 1) / kTeamTile;
   const int64_t rounds = (tiles + 2 * (int64_t)gridDim.x - 1) / (2 * (int64_t)gridDim.x);
   auto tile_of = [&](int64_t r) { return (r * gridDim.x + blockIdx.x) * 2 + team; };
-  float4 x_next = load_x(tile_of(0) * kTeamTile);  // beyond n -> zeros
+  // target of the team's tile, one coordinate per lane of the first half-wave (prefetched with x:
+  // a load issued where the loss needs it would expose its whole latency inside a segment)
+  auto load_t = [&](int64_t m0, int tid) {
+    return (TRAIN && tid < kTeamTile && m0 + tid < a.n) ? a.target[m0 + tid] : 0.f;
+  };
+  // dx of a tile leaves one tile late, right after the NEXT tile's loads were issued: the wait
+  // for x_next at S0 then never has a freshly issued store in front of it
+  const int dx_kb = w >> 1, dx_cb = w & 1;  // 2 x 2 tiles of 16 x 16: features x coordinates
+  f32x4 dx_pend = {0.f, 0.f, 0.f, 0.f};
+  int64_t dx_m0 = -1;
+  auto flush_dx = [&](int lane) {
+    if (dx_m0 < 0) return;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t m = dx_m0 + dx_cb * 16 + l15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = dx_kb * 16 + lq * 4 + q;
+      if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[q];
+    }
+    dx_m0 = -1;
+  };
+  float4 x_next = load_x(tile_of(0) * kTeamTile, tid);  // beyond n -> zeros
+  float t_next = load_t(tile_of(0) * kTeamTile, tid);
 
   __syncthreads();  // weights resident
-  if (TRAIN && team == 1) {  // stagger: team 1 runs four segments behind team 0
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-  }
+  if (TRAIN && team == 1)  // stagger: team 1 runs `stagger` segments behind team 0
+    for (int q = 0; q < a.stagger; ++q) __syncthreads();
+  PROF_BEGIN
   for (int64_t r = 0; r < rounds; ++r) {
     // a team without a tile in the last round still walks the segments (rows >= n are inert)
     const int64_t m0 = tile_of(r) * kTeamTile;
-    __syncthreads();  // S0
+    // thread indices re-derived per tile from an opaque copy: hipcc otherwise keeps ~30 address
+    // registers (one per LDS access pattern below) alive across the whole loop
+    int tid_opaque = tid_outer;
+    asm volatile("" : "+v"(tid_opaque));
+    const int tid = tid_opaque, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    PROF_SYNC(0)  // S0
     {
       const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
       float* dst = tm.xs + c4 * S::ldx + k;
       dst[0] = x_next.x, dst[S::ldx] = x_next.y, dst[2 * S::ldx] = x_next.z,
       dst[3 * S::ldx] = x_next.w;
     }
-    if (r + 1 < rounds) x_next = load_x(tile_of(r + 1) * kTeamTile);
-    __syncthreads();  // S1: layer 1
+    const float t_cur = t_next;
+    if (r + 1 < rounds) {
+      x_next = load_x(tile_of(r + 1) * kTeamTile, tid);
+      t_next = load_t(tile_of(r + 1) * kTeamTile, tid);
+    }
+    if (TRAIN) flush_dx(lane);
+    PROF_SYNC(1)  // S1: layer 1
     {
       f32x16 acc[1][1];
       zero(acc);
@@ -515,7 +612,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       for (int q = 0; q < 16; ++q)
         tm.h1[acc_row(q, lh) * S::lda + col] = fmaxf(acc[0][0][q] + bias, 0.f);
     }
-    __syncthreads();  // S2: layer 2
+    PROF_SYNC(2)  // S2: layer 2
     {
       f32x16 acc[1][1];
       zero(acc);
@@ -527,7 +624,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       for (int q = 0; q < 16; ++q)
         tm.h2[acc_row(q, lh) * S::lda + col] = fmaxf(acc[0][0][q] + bias, 0.f);
     }
-    __syncthreads();  // S3: output layer, thread = (coordinate l31, eighth of H)
+    PROF_SYNC(3)  // S3: output layer, thread = (coordinate l31, eighth of H)
     {
       constexpr int Q = H / 8;
       const int part = w * 2 + lh;
@@ -538,7 +635,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       for (int o = 0; o < Q; ++o) sacc += row[o] * wv[o];
       tm.ypart[part * kTeamTile + l31] = sacc;
     }
-    __syncthreads();  // S4: prediction, loss, dy
+    PROF_SYNC(4)  // S4: prediction, loss, dy
     if (tid < kTeamTile) {
       const int64_t m = m0 + tid;
       float y = b3;
@@ -548,7 +645,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       if (m < a.n) {
         if (a.y) a.y[m] = y;
         if (TRAIN) {
-          const float diff = y - a.target[m];
+          const float diff = y - t_cur;
           loss += diff * diff;
           d = diff * a.grad_scale;
           g_b3 += d;
@@ -557,28 +654,36 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       tm.dy[tid] = d;
     }
     if (!TRAIN) continue;
-    __syncthreads();  // S5: dz2 in place, dW3 / db2 partials
+    PROF_SYNC(5)  // S5: dz2 in place, dW3 / db2 partials
     {
-      const int o = tid % H, c0 = (tid / H) * (kTeamTile / 2);
+      // all 16 + 16 reads first, then the arithmetic, then the 16 writes: a read -> write chain
+      // per coordinate would pay the LDS latency 16 times
+      constexpr int C = kTeamTile / 2;
+      const int o = tid % H, c0 = (tid / H) * C;
       const float w3o = sm.w3[o];
-#pragma unroll 8
-      for (int c = c0; c < c0 + kTeamTile / 2; ++c) {
-        const float h = tm.h2[c * S::lda + o];
-        const float d = tm.dy[c];
-        g_w3 += d * h;
-        const float dz = h > 0.f ? d * w3o : 0.f;
+      float hv[C], dv[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) hv[c] = tm.h2[(c0 + c) * S::lda + o];
+#pragma unroll
+      for (int c = 0; c < C; ++c) dv[c] = tm.dy[c0 + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        g_w3 += dv[c] * hv[c];
+        const float dz = hv[c] > 0.f ? dv[c] * w3o : 0.f;
         g_b2 += dz;
-        tm.h2[c * S::lda + o] = dz;
+        tm.h2[(c0 + c) * S::lda + o] = dz;
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the two running sums inside this segment
     }
-    __syncthreads();  // S6: dW2 += dz2^T h1 ; dz1 = dz2 W2 (accumulators only)
+    PROF_SYNC(6)  // S6: dW2 += dz2^T h1 ; dz1 = dz2 W2 (accumulators only)
     mfma32<1, 4>(g_w2, tm.h2 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
                  tm.h1 + l31 + lh * S::lda, 32, 2 * S::lda, kTeamTile / 2);
     f32x16 dz1[1][1];
     zero(dz1);
     mfma32<1, 1>(dz1, tm.h2 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) + lh * S::ldw2, 0,
                  2 * S::ldw2, H / 2);
-    __syncthreads();  // S7: dz1 = (.) * (h1 > 0) over h1
+    PROF_SYNC(7)  // S7: dz1 = (.) * (h1 > 0) over h1
     {
       const int col = w * 32 + l31;
 #pragma unroll
@@ -589,33 +694,58 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
         *p = v;
       }
     }
-    __syncthreads();  // S8: dW1 += dz1^T x ; dx^T = W1^T dz1^T
-    mfma32<1, 1>(g_w1, tm.h1 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
-                 tm.xs + l31 + lh * S::ldx, 0, 2 * S::ldx, kTeamTile / 2);
+    PROF_SYNC(8)  // S8: dW1 += dz1^T x ; dx^T = W1^T dz1^T
     if (a.dx) {
+      // one wave per SIMD works here (the other team sits in a short segment), so nothing but
+      // this wave's own pipelining hides the LDS latency: the first dx group is fetched before
+      // dW1's MFMAs, every later group before the MFMAs of the group in front of it
+      constexpr int U = 4;
       const int l15 = lane & 15, lq = lane >> 4;
-      const int kb = w >> 1, cb = w & 1;  // 2 x 2 tiles of 16 x 16: features x coordinates
+      const float* pa = sm.w1 + lq * S::ldw1 + dx_kb * 16 + l15;
+      const float* pb = tm.h1 + (dx_cb * 16 + l15) * S::lda + lq;
+      float xa[2][U], xb[2][U];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* pa = sm.w1 + lq * S::ldw1 + kb * 16 + l15;
-      const float* pb = tm.h1 + (cb * 16 + l15) * S::lda + lq;
-#pragma unroll 8
-      for (int st = 0; st < H / 4; ++st)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[st * 4 * S::ldw1], pb[st * 4], acc, 0, 0, 0);
-      const int64_t m = m0 + cb * 16 + l15;
+      auto fetch = [&](int buf, int s0) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = kb * 16 + lq * 4 + q;
-        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = acc[q];
+        for (int u = 0; u < U; ++u) {
+          xa[buf][u] = pa[(s0 + u) * 4 * S::ldw1];
+          xb[buf][u] = pb[(s0 + u) * 4];
+        }
+      };
+      auto compute = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[buf][u], xb[buf][u], acc, 0, 0, 0);
+      };
+      static_assert((H / 4) % (2 * U) == 0, "dx steps come in pairs of groups");
+      fetch(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma32<1, 1>(g_w1, tm.h1 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                   tm.xs + l31 + lh * S::ldx, 0, 2 * S::ldx, kTeamTile / 2);
+#pragma unroll
+      for (int st = 0; st < H / 4; st += 2 * U) {
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1, st + U);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 * U < H / 4) fetch(0, st + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
       }
+      dx_pend = acc;
+      dx_m0 = m0;
+    } else {
+      mfma32<1, 1>(g_w1, tm.h1 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+                   tm.xs + l31 + lh * S::ldx, 0, 2 * S::ldx, kTeamTile / 2);
     }
   }
   if (!TRAIN) return;
-  if (team == 0) {
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-  }
+  PROF_MARK(18)
+  PROF_END(threadIdx.x >> 6)
+  flush_dx(lane);
+  if (team == 0)
+    for (int q = 0; q < a.stagger; ++q) __syncthreads();
   __syncthreads();  // both teams are done with their activation images
 
   // ---- one slab per team ------------------------------------------------------------------
@@ -799,6 +929,7 @@ static int tiny_mlp_train_impl(int overwrite, const float* x, const float* targe
   a.n = n, a.k_in = k_in;
   a.grad_scale = (float)(2.0 / ((double)n * (double)grad_divisor));
   a.inv_n = (float)(1.0 / (double)n);
+  a.stagger = std::min(std::max(options().mlp_stagger, 0), 8);
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
   r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7, r.overwrite = overwrite;
@@ -838,3 +969,12 @@ extern "C" int mri_tiny_mlp_train_overwrite(const float* x, const float* target,
                              d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
                              workspace_bytes, stream);
 }
+
+#ifdef MRI_MLP_PROFILE
+extern "C" int mri_debug_set_mlp_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mri::g_mlp_profile), &device_buffer, sizeof(device_buffer)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#endif

@@ -170,6 +170,8 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
     options().bwd_lds_max_parts = value;
   } else if (!strcmp(name, "bwd_dense_max_parts")) {
     options().bwd_dense_max_parts = value;
+  } else if (!strcmp(name, "mlp_stagger")) {
+    options().mlp_stagger = value;
   } else if (!strcmp(name, "bwd_blocks_per_level")) {
     options().bwd_blocks_per_level = value < 1 ? 1 : value;
   } else {
