@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=500,
                     help="total training steps before the PSNR evaluation (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="produce every batch on the main stream at the start of its step")
     ap.add_argument("--phase-every", type=int, default=8,
                     help="bracket the phases with HIP events on every n-th timed step only: "
                          "an event pair stalls the queue ~15 us, 5 pairs per step cost 8 %%")
@@ -142,7 +144,7 @@ def main():
     vol = datamodules.phantom_volume(w["shape"], device=dev)
     ds = datamodules.MriImage(volume=vol, norm_siren=w["norm_siren"], device=dev)
     lo, hi = parallel.voxel_range(ds.shape, rank, world)
-    loader = datamodules.DeviceLoader(ds, w["batch"], shuffle=True, lo=lo, hi=hi,
+    loader = datamodules.DeviceLoader(ds, w["batch"], shuffle=True, lo=lo, hi=hi, drop_last=True,
                                       seed=1337 + rank)
     model = build_model(w).to(dev)
     opt = model.configure_optimizers()
@@ -151,24 +153,27 @@ def main():
     if args.grad_buckets:
         step.grad_buckets = args.grad_buckets
     n_params = sum(p.numel() for p in model.parameters())
-    coords = torch.empty(w["batch"], 3, device=dev)
-    target = torch.empty(w["batch"], 1, device=dev)
-    per_epoch = (hi - lo) // w["batch"]
     counter = [0]
-
     events = {}
     sampling = [False]
+    # shuffled batches, epoch after epoch; batch k+1 is produced while step k runs (queued on
+    # the step's side stream, or after Adam when the step has none): its kernels still execute
+    # inside the timed region
+    pipe = datamodules.BatchPipeline(loader)
 
     def one_step():
         k = counter[0]
         counter[0] += 1
-        loader.set_epoch(k // per_epoch)
         step.phase_events = events if sampling[0] and (k - args.warmup) % max(1, args.phase_every) == 0 \
             else None
-        with step._phase("coord_gen"):
-            idx = loader.indices((k % per_epoch) * w["batch"], w["batch"])
-            ds.batch(idx, coords, target)
-        return step.train_step(coords, target)
+        coords, target = pipe.current()
+        if args.no_prefetch:
+            loss = step.train_step(coords, target)
+            pipe.produce_next()
+        else:
+            loss = step.train_step(coords, target, pipe.produce_next)
+        pipe.advance()
+        return loss
 
     for _ in range(args.warmup):
         one_step()

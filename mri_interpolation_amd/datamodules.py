@@ -12,6 +12,7 @@ range (a without-replacement shuffle, one key per epoch) and a gather that turns
 indices into (coords, targets) through per-axis `torch.linspace` tables built on the host
 (so coordinates equal the reference's bit for bit, SURVEY.md section 7 hard part 6).
 """
+import itertools
 import math
 from typing import Optional, Sequence
 
@@ -121,19 +122,91 @@ class DeviceLoader:
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
-    def indices(self, first: int, n: int) -> torch.Tensor:
+    def indices(self, first: int, n: int, epoch: Optional[int] = None, out=None) -> torch.Tensor:
+        epoch = self.epoch if epoch is None else epoch
         if self.shuffle:
-            return ops.sample_indices(self.seed + 7919 * self.epoch, first, self.lo, self.hi, n,
-                                      device=self.ds.device)
-        return torch.arange(self.lo + first, self.lo + first + n, device=self.ds.device)
+            return ops.sample_indices(self.seed + 7919 * epoch, first, self.lo, self.hi, n,
+                                      out=out, device=self.ds.device)
+        idx = torch.arange(self.lo + first, self.lo + first + n, device=self.ds.device)
+        return idx if out is None else out.copy_(idx)
+
+    def span(self, b: int):
+        """(first voxel of batch b within [lo, hi), its size)."""
+        first = b * self.batch_size
+        return first, min(self.batch_size, self.hi - self.lo - first)
+
+    def batches(self, n_batches: Optional[int] = None):
+        """Generator over `n_batches` consecutive batches (default: one epoch; -1: endless),
+        running on into the following epochs; advances `self.epoch` as epochs complete."""
+        per_epoch = len(self)
+        if per_epoch == 0:
+            return
+        epoch0 = self.epoch
+        count = itertools.count() if (n_batches is not None and n_batches < 0) \
+            else range(per_epoch if n_batches is None else n_batches)
+        for k in count:
+            epoch, b = epoch0 + k // per_epoch, k % per_epoch
+            first, n = self.span(b)
+            self.epoch = epoch
+            yield self.ds.batch(self.indices(first, n, epoch))
+            if b == per_epoch - 1:
+                self.epoch = epoch + 1
 
     def __iter__(self):
-        total = self.hi - self.lo
-        for b in range(len(self)):
-            first = b * self.batch_size
-            n = min(self.batch_size, total - first)
-            yield self.ds.batch(self.indices(first, n))
-        self.epoch += 1
+        return self.batches()
+
+
+class BatchPipeline:
+    """Two reused batch buffers for a training loop: while step k consumes buffer k % 2, batch
+    k+1 is produced into the other one by `produce_next()`, which the caller runs on whatever
+    stream has room beside the step -- FusedStep queues it on its side stream right after the
+    counting stage of the table gradient, whose completion the main stream awaits anyway (no
+    extra cross-stream wait, which costs ~12 us of queue bubble on this GPU).  The counterpart
+    of the reference DataLoader's worker processes (datamodules.py:198-205).
+
+    Ordering contract: produce_next() for batch k+1 must be queued after step k-1 has finished
+    with that buffer (true for any stream that waited on the main stream during step k), and
+    step k+1 must wait for it (FusedStep's wait for the side stream before the scatter)."""
+
+    def __init__(self, loader: DeviceLoader):
+        self.loader = loader
+        dev, bs = loader.ds.device, loader.batch_size
+        self.slots = [(torch.empty(bs, dtype=torch.int64, device=dev),
+                       torch.empty(bs, loader.ds.dim_in, device=dev),
+                       torch.empty(bs, 1, device=dev)) for _ in range(2)]
+        self.per_epoch = len(loader)
+        if self.per_epoch == 0:
+            raise ValueError("empty loader")
+        self.epoch0 = loader.epoch
+        self.k = 0
+        self.sizes = [0, 0]
+        self._produce(0)  # on the current stream
+
+    def _produce(self, k: int):
+        epoch, b = self.epoch0 + k // self.per_epoch, k % self.per_epoch
+        first, n = self.loader.span(b)
+        idx, coords, target = self.slots[k % 2]
+        self.loader.ds.batch(self.loader.indices(first, n, epoch, out=idx[:n]), coords[:n],
+                             target[:n])
+        self.sizes[k % 2] = n
+
+    def current(self):
+        """(coords, targets) of batch k; valid until advance() + produce_next()."""
+        _, coords, target = self.slots[self.k % 2]
+        n = self.sizes[self.k % 2]
+        return coords[:n], target[:n]
+
+    def produce_next(self):
+        """Queue the production of batch k+1 on the CURRENT stream."""
+        self._produce(self.k + 1)
+
+    def advance(self):
+        self.k += 1
+        self.loader.epoch = self.epoch0 + self.k // self.per_epoch
+
+    @property
+    def batch_in_epoch(self) -> int:
+        return self.k % self.per_epoch
 
 
 class GridLoader:

@@ -20,6 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import models, ops, optim, parallel
+from .datamodules import BatchPipeline, DeviceLoader
 
 
 class _Layer:
@@ -259,8 +260,10 @@ class FusedStep:
             with self._phase("hashgrid_bwd"):
                 self._pending = self._hash_backward(coords, ws["d_enc"])
 
-    def train_step(self, coords, target) -> torch.Tensor:
-        """One optimisation step; returns the (device) loss scalar of this rank's batch."""
+    def train_step(self, coords, target, side_work=None) -> torch.Tensor:
+        """One optimisation step; returns the (device) loss scalar of this rank's batch.
+        `side_work()` (e.g. BatchPipeline.produce_next) is queued where it overlaps the step:
+        on the side stream behind the counting stage when there is one, else after Adam."""
         if (self.encoder is not None and self.overlap_count and self.bwd_method != 1
                 and self.grad_buckets <= 1):
             if self._side is None:
@@ -270,6 +273,10 @@ class FusedStep:
             self._side.wait_stream(torch.cuda.current_stream())
             ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side)
             self._counted = True
+            if side_work is not None:
+                with torch.cuda.stream(self._side):
+                    side_work()
+                side_work = None
         _, ws = self.forward(coords, train=True)
         self._pending = []
         self.backward(coords, target, ws)
@@ -289,6 +296,8 @@ class FusedStep:
                     parallel.all_reduce_sum(self.flat.grad)
         with self._phase("adam"):
             self.opt.step()
+        if side_work is not None:
+            side_work()
         return self.loss
 
 
@@ -328,8 +337,20 @@ class Trainer:
             if hasattr(train_dataloaders, "set_epoch"):
                 train_dataloaders.set_epoch(epoch)
             t0, seen = time.perf_counter(), 0
-            for batch_idx, (x, y) in enumerate(train_dataloaders):
-                if self.fused is not None:
+            pipe = None
+            if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
+                    and len(train_dataloaders) > 0:
+                pipe = BatchPipeline(train_dataloaders)
+                batches = ((b,) + pipe.current() for b in range(len(train_dataloaders)))
+            else:
+                batches = ((b, x, y) for b, (x, y) in enumerate(train_dataloaders))
+            for batch_idx, x, y in batches:
+                if pipe is not None:
+                    last = batch_idx == len(train_dataloaders) - 1
+                    loss = self.fused.train_step(x, y, None if last else pipe.produce_next)
+                    if not last:
+                        pipe.advance()
+                elif self.fused is not None:
                     loss = self.fused.train_step(x, y)
                 else:
                     opt.zero_grad()

@@ -599,3 +599,29 @@ def test_bucketed_backward_equals_single_launch(amd):
     step.grad_buckets = 3
     step.backward(x, y, ws)
     assert len(step._pending) == 3 and torch.equal(step.flat.grad * 2, want)
+
+
+def test_batch_pipeline_yields_the_same_batches(amd):
+    """BatchPipeline produces batch k+1 on a side stream while k is consumed: same batches, in
+    the same order, as the plain loader -- across epochs, with a ragged last batch."""
+    vol = np.arange(7 * 6 * 5, dtype=np.float32).reshape(7, 6, 5)
+    ds = amd.datamodules.MriImage(volume=vol)
+    plain = amd.datamodules.DeviceLoader(ds, 64, shuffle=True, seed=5)
+    other = amd.datamodules.DeviceLoader(ds, 64, shuffle=True, seed=5)
+    want = [(x.clone(), y.clone()) for x, y in plain.batches(9)]
+    assert plain.epoch == 2 and len(plain) == 4 and want[3][0].shape[0] == 210 - 3 * 64
+    pipe = amd.datamodules.BatchPipeline(other)
+    side = torch.cuda.Stream()
+    burn = torch.empty(1 << 22, device="cuda")
+    main = torch.cuda.current_stream()
+    for k, (x0, y0) in enumerate(want):
+        x, y = pipe.current()
+        side.wait_stream(main)          # what FusedStep.train_step does before the count
+        with torch.cuda.stream(side):
+            pipe.produce_next()
+        if k % 2:
+            burn.normal_()              # the consumer's "step"
+        assert torch.equal(x, x0) and torch.equal(y, y0)
+        main.wait_stream(side)          # ... and before the scatter
+        pipe.advance()
+    assert other.epoch == 2 and pipe.batch_in_epoch == 1
