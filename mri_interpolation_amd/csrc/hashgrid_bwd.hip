@@ -27,7 +27,8 @@
 // Integer addition is associative: the table gradient is BITWISE REPRODUCIBLE (independent of
 // scheduling and of the order the records landed in), and more accurate than an f32 running sum
 // (>= 40 fraction bits below max|g|; |sum| <= n * max|g| < 2^61 cannot overflow).
-// Algorithmic traffic: records are 4*(1+F) bytes, written once and read once.
+// Algorithmic traffic: records are 2 + 4 F bytes (16-bit slot within the slice + F values),
+// written once and read once.
 #include <algorithm>
 
 #include "hashgrid_common.h"
@@ -36,6 +37,7 @@ namespace mri {
 namespace {
 
 constexpr int kAccWords = 16384;  // 128 KiB of u64 accumulators per accumulate workgroup
+static_assert(kAccWords <= 65536, "record slots are stored in 16 bits");
 constexpr int kAccThreads = 1024;
 constexpr int kStageWords = 12288;  // 48 KiB LDS staging buffer of the scatter kernel (2 workgroups/CU)
 constexpr int kBinThreads = 512;
@@ -65,7 +67,7 @@ struct Workspace {  // carved out of the caller's buffer
   uint32_t* chunk_base;  // [total_bins][chunks] where the chunk's run starts inside the bin
   unsigned long long* partial;  // [ws_words]   cleared at the start of every call
   int64_t partial_words;
-  uint32_t* rec_slot;   // [records]
+  uint16_t* rec_slot;   // [records] slot within the bin's slice (< 2^14: kAccWords / F slots)
   float* rec_val;       // [F][records]
   int64_t records;
 };
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
     const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
     uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_base,
-    const uint32_t* __restrict__ offsets, int chunks, uint32_t* __restrict__ rec_slot,
+    const uint32_t* __restrict__ offsets, int chunks, uint16_t* __restrict__ rec_slot,
     float* __restrict__ rec_val, int64_t records, uint32_t* __restrict__ max_bits) {
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
     const uint64_t dst = (uint64_t)global_base[p];
     for (uint32_t k = lane; k < cnt; k += 64) {
-      rec_slot[dst + k] = stage[lo + k];
+      rec_slot[dst + k] = (uint16_t)stage[lo + k];
 #pragma unroll
       for (int f = 0; f < F; ++f)
         rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void bin_prefix_kernel(uint32_t* __restrict__ 
 template <int F>
 __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ rec_slot,
+    const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
     const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
     unsigned long long* __restrict__ partial, int overwrite) {
@@ -320,21 +322,21 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  // 4 records per lane and load (16-byte accesses: r_lo, k_lo and `records` are multiples of 4),
+  // 4 records per lane and load (8- and 16-byte accesses: r_lo, k_lo and `records` are multiples of 4),
   // kGroups such loads per array in flight before the first LDS atomic: the kernel is latency
   // bound (78 % of wave cycles in s_waitcnt), not LDS bound
   constexpr int kGroups = 4;
   const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
-  const uint32_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
+  const uint16_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
   const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
   for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
-    uint4 rel[kGroups];
+    uint2 rel[kGroups];  // four 16-bit slots
     float4 val[kGroups][F];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
       const uint32_t k = k0 + g * 4 * kAccThreads;
       if (k < k_vec) {
-        rel[g] = *reinterpret_cast<const uint4*>(slot_ptr + k);
+        rel[g] = *reinterpret_cast<const uint2*>(slot_ptr + k);
 #pragma unroll
         for (int f = 0; f < F; ++f)
           val[g][f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k);
@@ -344,7 +346,8 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     for (int g = 0; g < kGroups; ++g) {
       const uint32_t k = k0 + g * 4 * kAccThreads;
       if (k < k_vec) {
-        const uint32_t r4[4] = {rel[g].x, rel[g].y, rel[g].z, rel[g].w};
+        const uint32_t r4[4] = {rel[g].x & 0xffffu, rel[g].x >> 16, rel[g].y & 0xffffu,
+                                rel[g].y >> 16};
 #pragma unroll
         for (int f = 0; f < F; ++f) {
           const float v4[4] = {val[g][f].x, val[g][f].y, val[g][f].z, val[g][f].w};
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
 // A level whose table is cut into only a few slices does not need records at all: a workgroup
 // (level, slice, coordinate range) can afford to evaluate the corners of every coordinate of its
 // range and add the ones that fall into its slice straight into LDS -- the redundancy is the
-// number of slices (<= bwd_dense_max_parts), against 24 bytes of record traffic per corner.
+// number of slices (<= bwd_dense_max_parts), against 20 bytes of record traffic per corner.
 // Ranges meet in the int64 workspace like the entry ranges of the binned levels.
 template <int F>
 __global__ __launch_bounds__(256) void dense_absmax_kernel(const BinPlan plan,
@@ -559,7 +562,7 @@ int64_t chunk_table_words(const BinPlan& plan, int64_t n) {
 
 int64_t workspace_bytes(const BinPlan& plan, int64_t n, int64_t ws_words, int64_t records, int F) {
   return (int64_t)kHeaderWords * 4 + 2 * (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 12 +
-         2 * chunk_table_words(plan, n) * 4 + ws_words * 8 + records * 4 * (1 + F) + 64;
+         2 * chunk_table_words(plan, n) * 4 + ws_words * 8 + records * (2 + 4 * F) + 80;
 }
 
 // Fixed-position regions first, the record area next, the int64 area at the END of the buffer.
@@ -580,8 +583,8 @@ Workspace carve(void* base, int64_t total_bytes, const BinPlan& plan, int64_t n,
   p += table * 4;
   w.chunk_base = reinterpret_cast<uint32_t*>(p);
   p += table * 4;
-  w.rec_slot = reinterpret_cast<uint32_t*>(p);
-  p += records * 4;
+  w.rec_slot = reinterpret_cast<uint16_t*>(p);
+  p += (records * 2 + 15) / 16 * 16;
   w.rec_val = reinterpret_cast<float*>(p);
   w.records = records;
   const int64_t tail = (total_bytes - ws_words * 8) & ~int64_t(15);
