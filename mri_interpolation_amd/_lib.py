@@ -15,6 +15,8 @@ BWD_PREPARED = 16
 BWD_OVERWRITE = 32
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmri_inr.so")
+if os.environ.get("MRI_LIB"):  # tuning: an alternative build of the same sources (tools/)
+    _LIB_PATH = os.environ["MRI_LIB"]
 
 
 class GridDesc(C.Structure):
