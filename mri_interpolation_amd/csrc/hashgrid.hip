@@ -116,12 +116,18 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
   float* __restrict__ o = out + (int64_t)level * sl + i * sr;
   if constexpr (F == 2) {
     if (sf == 1 && ((reinterpret_cast<uintptr_t>(o)) & 7) == 0) {
-      *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[1]);
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      f2v v2;
+      v2.x = acc[0], v2.y = acc[1];
+      __builtin_nontemporal_store(v2, reinterpret_cast<f2v*>(o));
       return;
     }
   }
 #pragma unroll
-  for (int f = 0; f < F; ++f) o[f * sf] = acc[f];
+  for (int f = 0; f < F; ++f) {
+    // written once, read by another kernel: keep it out of the L2 that holds the tables
+    __builtin_nontemporal_store(acc[f], o + f * sf);
+  }
 }
 
 // ------------------------------------------------------------------- backward, global atomics

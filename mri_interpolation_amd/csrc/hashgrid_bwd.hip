@@ -336,10 +336,17 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     for (int g = 0; g < kGroups; ++g) {
       const uint32_t k = k0 + g * 4 * kAccThreads;
       if (k < k_vec) {
-        rel[g] = *reinterpret_cast<const uint2*>(slot_ptr + k);
+        // read once: non-temporal loads leave the L2 to the gradient slices written below (25 us)
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const u2v r_ = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(slot_ptr + k));
+        rel[g] = make_uint2(r_.x, r_.y);
 #pragma unroll
-        for (int f = 0; f < F; ++f)
-          val[g][f] = *reinterpret_cast<const float4*>(val_ptr + (uint64_t)f * records + k);
+        for (int f = 0; f < F; ++f) {
+          const f4v v_ = __builtin_nontemporal_load(
+              reinterpret_cast<const f4v*>(val_ptr + (uint64_t)f * records + k));
+          val[g][f] = make_float4(v_.x, v_.y, v_.z, v_.w);
+        }
       }
     }
 #pragma unroll
