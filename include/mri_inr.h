@@ -115,6 +115,16 @@ int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x, const float
                           int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
                           int64_t dout_feat_stride, float* d_table, int32_t method,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* Same, for the levels whose bit is set in `level_mask` only (bit l = level l): the gradient of
+ * one level group at a time, so that a data-parallel caller can start reducing a finished group
+ * (all-reduce over RCCL) while the next one is computed.  With MRI_BWD_PREPARED one
+ * mri_hashgrid_backward_prepare call on the workspace serves every group; without it each call
+ * recounts all levels.  Rows of levels outside the mask are not touched. */
+int mri_hashgrid_backward_levels(const mri_grid_desc* grid, const float* x, const float* d_out,
+                                 int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
+                                 int64_t dout_feat_stride, float* d_table, int32_t method,
+                                 uint32_t level_mask, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
 
 /* ---- fully connected layers (f32 MFMA) ------------------------------------------------
  * y = act(w0 * (x W^T + b))   with W (N, K) row-major as nn.Linear / SirenLayer store it.

@@ -44,6 +44,8 @@ SIGNATURES = {
     "mri_hashgrid_forward": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _I64, _P],
     "mri_hashgrid_backward": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32, _P,
                               _I64, _P],
+    "mri_hashgrid_backward_levels": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32,
+                                     C.c_uint32, _P, _I64, _P],
     "mri_hashgrid_backward_prepare": [C.POINTER(GridDesc), _P, _I64, _I32, _P, _I64, _P],
     "mri_linear_forward": [_P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _P, _I64, _P,
                            _I64, _P],

@@ -600,11 +600,32 @@ Workspace carve(void* base, int64_t total_bytes, const BinPlan& plan, int64_t n,
   return w;
 }
 
+// The entries of `plan` whose level is in `mask`, for the launches of one level group: positions
+// in the record / bin / int64 areas stay those of the full plan (so one prepare call serves every
+// group), only the workgroup -> entry map (acc_start) is renumbered.
+BinPlan select_levels(const BinPlan& plan, uint32_t mask, int& blocks) {
+  BinPlan sel = plan;
+  sel.n_entries = 0;
+  blocks = 0;
+  for (int e = 0; e < plan.n_entries; ++e) {
+    if (!((mask >> plan.level_of[e]) & 1u)) continue;
+    const int k = sel.n_entries++;
+    sel.level_of[k] = plan.level_of[e];
+    sel.parts[k] = plan.parts[e];
+    sel.bin_start[k] = plan.bin_start[e];
+    sel.splits[k] = plan.splits[e];
+    sel.ws_offset[k] = plan.ws_offset[e];
+    sel.acc_start[k] = blocks;
+    blocks += plan.parts[e] * plan.splits[e];
+    sel.acc_start[k + 1] = blocks;
+  }
+  return sel;
+}
+
 template <int D, int F>
 struct BinnedLaunch {
-  static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense, int dense_blocks,
-                 const Workspace& w, int n_levels, int acc_blocks, bool any_split, int phase,
-                 int overwrite,
+  static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense_all,
+                 const Workspace& w, int n_levels, uint32_t level_mask, int phase, int overwrite,
                  const float* x, const float* d_out, int64_t n, int64_t sl, int64_t sr,
                  int64_t sf, float* d_table, hipStream_t st) {
     // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
@@ -619,6 +640,12 @@ struct BinnedLaunch {
         if (w.partial_words > 0)
           (void)hipMemsetAsync(w.partial, 0, (size_t)w.partial_words * 8, st);
       }
+      // phase 1 counts every level; the gradient launches below cover the levels of the mask
+      int dense_blocks = 0, acc_blocks = 0;
+      const BinPlan dense = select_levels(dense_all, level_mask, dense_blocks);
+      const BinPlan sel = select_levels(plan, level_mask, acc_blocks);
+      bool any_split = false;
+      for (int e = 0; e < sel.n_entries; ++e) any_split |= sel.ws_offset[e] >= 0;
       if (dense.n_entries > 0 && phase != 1) {
         hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
                            dense, d_out, n, sl, sr, sf, w.max_bits);
@@ -641,15 +668,17 @@ struct BinnedLaunch {
                            w.counts, plan.total_bins);
       }
       if (phase == 1) return check_launch("hashgrid backward (count)");
-      hipLaunchKernelGGL((bin_kernel<D, F, true>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
-                         x, d_out, n, sl, sr, sf, w.chunk_hist, w.chunk_base, w.offsets, chunks,
-                         w.rec_slot, w.rec_val, w.records, w.max_bits);
+      if (sel.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
+      hipLaunchKernelGGL((bin_kernel<D, F, true>), dim3((unsigned)chunks, sel.n_entries),
+                         dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
+                         w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
+                         w.records, w.max_bits);
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
-                         dim3(kAccThreads), 0, st, tab, plan, n, w.offsets, w.counts, w.rec_slot,
+                         dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts, w.rec_slot,
                          w.rec_val, w.records, w.max_bits, d_table, w.partial, overwrite);
       if (any_split)
-        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, plan.n_entries), dim3(256), 0, st, tab,
-                           plan, F, n, d_table, w.max_bits, w.partial, overwrite);
+        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, sel.n_entries), dim3(256), 0, st, tab,
+                           sel, F, n, d_table, w.max_bits, w.partial, overwrite);
       return check_launch("hashgrid backward (binned)");
     } else {
       return fail(MRI_ERR_UNSUPPORTED, "binned backward supports dim <= 4, n_features <= 4");
@@ -676,7 +705,8 @@ extern "C" int64_t mri_hashgrid_backward_workspace_bytes(const mri_grid_desc* gr
 namespace {
 int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
                   int64_t sl, int64_t sr, int64_t sf, float* d_table, int32_t method, int phase,
-                  int overwrite, void* workspace, int64_t workspace_bytes_given, void* stream) {
+                  int overwrite, uint32_t level_mask, void* workspace,
+                  int64_t workspace_bytes_given, void* stream) {
   if (int rc = validate(grid)) return rc;
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
@@ -699,13 +729,12 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
                 "workspace must be 16-byte aligned");
     const Workspace w = carve(workspace, workspace_bytes_given, plan, n, ws_words, records, F);
     const LevelTab tab = make_tab(grid);
-    bool any_split = false;
-    for (int e = 0; e < plan.n_entries; ++e) any_split |= plan.ws_offset[e] >= 0;
-    int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, dense_blocks, w,
-                                    grid->n_levels, acc_blocks, any_split, phase, overwrite, x,
-                                    d_out, n, sl, sr, sf, d_table, (hipStream_t)stream);
+    int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, w, grid->n_levels,
+                                    level_mask, phase, overwrite, x, d_out, n, sl, sr, sf,
+                                    d_table, (hipStream_t)stream);
     if (rc) return rc;
   }
+  atomic_mask &= level_mask;
   if (atomic_mask && phase != 1) {
     if (overwrite)  // the atomic kernel can only add: clear its levels first
       for (int l = 0; l < grid->n_levels; ++l)
@@ -722,7 +751,7 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
 extern "C" int mri_hashgrid_backward_prepare(const mri_grid_desc* grid, const float* x, int64_t n,
                                              int32_t method, void* workspace,
                                              int64_t workspace_bytes, void* stream) {
-  return backward_impl(grid, x, nullptr, n, 0, 0, 0, nullptr, method, 1, 0, workspace,
+  return backward_impl(grid, x, nullptr, n, 0, 0, 0, nullptr, method, 1, 0, 0xffffffffu, workspace,
                        workspace_bytes, stream);
 }
 
@@ -731,9 +760,20 @@ extern "C" int mri_hashgrid_backward(const mri_grid_desc* grid, const float* x,
                                      int64_t dout_row_stride, int64_t dout_feat_stride,
                                      float* d_table, int32_t method, void* workspace,
                                      int64_t workspace_bytes_given, void* stream) {
+  return mri_hashgrid_backward_levels(grid, x, d_out, n, dout_level_stride, dout_row_stride,
+                                      dout_feat_stride, d_table, method, 0xffffffffu, workspace,
+                                      workspace_bytes_given, stream);
+}
+
+extern "C" int mri_hashgrid_backward_levels(const mri_grid_desc* grid, const float* x,
+                                            const float* d_out, int64_t n,
+                                            int64_t dout_level_stride, int64_t dout_row_stride,
+                                            int64_t dout_feat_stride, float* d_table,
+                                            int32_t method, uint32_t level_mask, void* workspace,
+                                            int64_t workspace_bytes_given, void* stream) {
   const int phase = (method & MRI_BWD_PREPARED) ? 2 : 0;
   const int overwrite = (method & MRI_BWD_OVERWRITE) ? 1 : 0;
   return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
                        d_table, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, overwrite,
-                       workspace, workspace_bytes_given, stream);
+                       level_mask, workspace, workspace_bytes_given, stream);
 }

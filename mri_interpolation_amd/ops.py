@@ -117,8 +117,11 @@ def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, 
 
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                       d_table: torch.Tensor, feature_major: bool = False, method: int = 0,
-                      prepared: bool = False, overwrite: bool = False):
-    """d_table += scatter of d_out (or d_table = ..., with overwrite=True)."""
+                      prepared: bool = False, overwrite: bool = False,
+                      level_mask: Optional[int] = None):
+    """d_table += scatter of d_out (or d_table = ..., with overwrite=True); `level_mask`
+    restricts the call to the levels whose bit is set (one level group of a bucketed,
+    data-parallel backward)."""
     _gpu(x, d_out, d_table)
     x = _rowmajor(x).contiguous()
     n = x.shape[0]
@@ -128,9 +131,14 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
     ws = backward_workspace(desc, n, x.device) if method != 1 else None
     flags = (method | (_lib.BWD_PREPARED if prepared else 0)
              | (_lib.BWD_OVERWRITE if overwrite else 0))
-    _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
-              _ptr(d_table), flags, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
-              _stream())
+    if level_mask is None:
+        _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
+                  _ptr(d_table), flags, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
+                  _stream())
+    else:
+        _lib.call("mri_hashgrid_backward_levels", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr,
+                  sf, _ptr(d_table), flags, level_mask & 0xFFFFFFFF, _ptr(ws),
+                  ws.numel() * 8 if ws is not None else 0, _stream())
     return d_table
 
 

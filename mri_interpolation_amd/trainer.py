@@ -171,44 +171,57 @@ class FusedStep:
                 feature_major = False
         return x, ws
 
-    def _level_buckets(self, n: int):
-        """[(sub-descriptor, first level, flat-gradient slice)] for the current bucket count."""
+    def _level_buckets(self):
+        """[(level mask, flat-gradient slice)] in execution order for the current bucket count.
+
+        Every level costs the same to compute (same number of corners) but its all-reduce costs
+        its table size, and only the LAST group's reduction cannot hide behind later compute.  So
+        the full-size (hashed) levels are cut into grad_buckets - 1 contiguous groups that run
+        first, finest first, and the coarse levels -- a few per cent of the bytes -- go last."""
         enc = self.encoder
-        key = (self.grad_buckets, n)
-        if self._bucket_cache is not None and self._bucket_cache[0] == key:
+        if self._bucket_cache is not None and self._bucket_cache[0] == self.grad_buckets:
             return self._bucket_cache[1]
-        groups = max(1, min(self.grad_buckets, enc.n_levels))
-        bounds = [round(g * enc.n_levels / groups) for g in range(groups + 1)]
+        sizes, n_levels = list(enc.sizes), enc.n_levels
+        groups = max(1, min(self.grad_buckets, n_levels))
+        first_full = n_levels
+        while first_full > 0 and sizes[first_full - 1] == max(sizes):
+            first_full -= 1
+        if groups >= 2 and 0 < first_full and n_levels - first_full >= groups - 1:
+            k = groups - 1
+            cuts = [first_full + round(g * (n_levels - first_full) / k) for g in range(k + 1)]
+            ranges = [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1] + [(0, first_full)]
+        else:
+            cuts = [round(g * n_levels / groups) for g in range(groups + 1)]
+            ranges = [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1]
         table_off = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
                                            if q is enc.table)]
+        f = enc.n_features_per_level
         out = []
-        for lo, hi in zip(bounds, bounds[1:]):
-            desc = ops.make_grid_desc(enc.dim, enc.resolutions[lo:hi], enc.sizes[lo:hi],
-                                      enc.n_features_per_level)
+        for lo, hi in ranges:
             row_lo, row_hi = enc._row_span(lo)[0], enc._row_span(hi - 1)[1]
-            for l in range(hi - lo):  # offsets stay absolute: the gradient base pointer is shared
-                desc.table_offset[l] = enc._row_span(lo + l)[0]
-            f = enc.n_features_per_level
-            out.append((desc, lo, self.flat.grad[table_off + row_lo * f:table_off + row_hi * f]))
-        self._bucket_cache = (key, out)
+            mask = sum(1 << l for l in range(lo, hi))
+            out.append((mask, self.flat.grad[table_off + row_lo * f:table_off + row_hi * f]))
+        self._bucket_cache = (self.grad_buckets, out)
         return out
 
     def _hash_backward(self, coords, d_enc, overwrite=False):
         """Table gradient; with several ranks, reduce each finished level group right away."""
-        enc, n = self.encoder, coords.shape[0]
+        enc = self.encoder
+        if self._counted:
+            torch.cuda.current_stream().wait_stream(self._side)
+        counted, self._counted = self._counted, False
         if self.grad_buckets <= 1:
-            if self._counted:
-                torch.cuda.current_stream().wait_stream(self._side)
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
-                                  method=self.bwd_method, prepared=self._counted,
-                                  overwrite=overwrite)
-            self._counted = False
+                                  method=self.bwd_method, prepared=counted, overwrite=overwrite)
             return []
+        if not counted and self.bwd_method != 1:  # one count for all the groups
+            ops.hashgrid_backward_prepare(enc.desc, coords, self.bwd_method)
+            counted = True
         pending = []
-        rows_per_level = enc.n_features_per_level
-        for desc, first, grad_slice in self._level_buckets(n):
-            ops.hashgrid_backward(desc, coords, d_enc[first * rows_per_level:], self._table_grad,
-                                  feature_major=True, method=self.bwd_method, overwrite=overwrite)
+        for mask, grad_slice in self._level_buckets():
+            ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
+                                  method=self.bwd_method, prepared=counted, overwrite=overwrite,
+                                  level_mask=mask)
             pending.append(parallel.all_reduce_async(grad_slice))
         return pending
 
@@ -264,8 +277,7 @@ class FusedStep:
         """One optimisation step; returns the (device) loss scalar of this rank's batch.
         `side_work()` (e.g. BatchPipeline.produce_next) is queued where it overlaps the step:
         on the side stream behind the counting stage when there is one, else after Adam."""
-        if (self.encoder is not None and self.overlap_count and self.bwd_method != 1
-                and self.grad_buckets <= 1):
+        if self.encoder is not None and self.overlap_count and self.bwd_method != 1:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=coords.device)
             # after the coordinates exist and after the previous step's backward released the

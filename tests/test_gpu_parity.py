@@ -599,6 +599,53 @@ def test_bucketed_backward_equals_single_launch(amd):
     step.grad_buckets = 3
     step.backward(x, y, ws)
     assert len(step._pending) == 3 and torch.equal(step.flat.grad * 2, want)
+    # the coarse levels (a few per cent of the bytes) form the last group
+    masks = [m for m, _ in step._level_buckets()]
+    assert masks[-1] & 1 and sum(masks) == (1 << 16) - 1 and len(set(masks)) == 3
+    # whole steps: one count on the side stream serves all the groups -> same parameters
+    import copy
+    nets = [copy.deepcopy(net) for _ in range(2)]
+    steps = [amd.trainer.FusedStep(m, m.configure_optimizers()) for m in nets]
+    steps[1].grad_buckets = 4
+    for _ in range(3):
+        for st in steps:
+            st.train_step(x, y)
+    assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+
+
+def test_backward_level_mask(amd):
+    """mri_hashgrid_backward_levels: the levels of the mask get exactly the gradient of the
+    full call, every other row of the buffer is left alone -- with and without a prepare call,
+    for binned, dense and (method 1) atomic levels."""
+    torch.manual_seed(4)
+    enc = amd.encoding.MultiResHashGrid(3, 16, 2, 19, 16, 512).cuda()
+    n = 20000
+    x = torch.rand(n, 3, device="cuda")
+    d = torch.randn(enc.output_dim, n, device="cuda")
+    full = torch.zeros_like(enc.table.data)
+    amd.ops.hashgrid_backward(enc.desc, x, d, full, feature_major=True, overwrite=True)
+    groups = [0b1111, 0xFF00, 0x00F0]
+    for prepared in (False, True):
+        for method in (0, 1):
+            got = torch.full_like(full, 5.0)
+            if prepared and method != 1:
+                amd.ops.hashgrid_backward_prepare(enc.desc, x, method)
+            for mask in groups:
+                amd.ops.hashgrid_backward(enc.desc, x, d, got, feature_major=True, method=method,
+                                          prepared=prepared and method != 1, overwrite=True,
+                                          level_mask=mask)
+            for level in range(16):
+                lo, hi = enc._row_span(level)
+                if method == 0:
+                    assert torch.equal(got[lo:hi], full[lo:hi]), (prepared, method, level)
+                else:
+                    assert_close(got[lo:hi].cpu().numpy(), full[lo:hi].cpu().numpy(), REL_TOL,
+                                 f"atomic level {level}")
+    # a mask without any level of the grid is a no-op
+    got = torch.full_like(full, 5.0)
+    amd.ops.hashgrid_backward(enc.desc, x, d, got, feature_major=True, overwrite=True,
+                              level_mask=1 << 20)
+    assert float(got.min()) == float(got.max()) == 5.0
 
 
 def test_batch_pipeline_yields_the_same_batches(amd):
