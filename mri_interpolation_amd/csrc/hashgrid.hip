@@ -131,6 +131,42 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(
 }
 
 // ------------------------------------------------------------------- backward, global atomics
+// F = 2, two lanes per (coordinate, level): lane 2i takes the corners with the LOWER vertex on
+// axis 0, lane 2i+1 those with the upper one.  PRIME_0 = 1, so the two slots of such a pair are
+// h and h ^ (x ^ (x+1)): they differ in the low bits only and share a 128-byte line unless
+// x = 15 (mod 16).  The kernel is bound by L1 line fills (one 128-byte fill per divergent lane
+// for 8 useful bytes); as neighbours of ONE load instruction the two requests are served by one
+// fill.  Each lane ends up owning one feature (its partial sum + the neighbour's, one DPP swap).
+template <int D>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(
+    const LevelTab tab, const Sched sched, const float* __restrict__ x, int64_t n,
+    const float* __restrict__ table, float* __restrict__ out, int64_t sl, int64_t sr,
+    int64_t sf) {
+  int level, chunk;
+  if (!decode(sched, level, chunk)) return;
+  const int64_t i = (int64_t)chunk * 128 + (threadIdx.x >> 1);
+  const int xc = threadIdx.x & 1;
+  const bool live = i < n;
+  const uint32_t size = tab.size[level], magic = tab.magic[level];
+  const bool pow2 = tab.pow2[level] != 0;
+  const float* __restrict__ rows = table + tab.offset[level] * 2;
+  const Cell<D> c = locate<D>(x, live ? i : n - 1, tab.res[level]);
+  float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < (1 << (D - 1)); ++nb) {
+    uint32_t h;
+    float w;
+    corner<D>(c, (nb << 1) | xc, h, w);
+    const float2 v = *reinterpret_cast<const float2*>(
+        rows + (uint64_t)slot_of(h, size, magic, pow2) * 2);
+    p0 = p0 + v.x * w;
+    p1 = p1 + v.y * w;
+  }
+  const float mine = xc ? p1 : p0, send = xc ? p0 : p1;
+  const float total = mine + __shfl_xor(send, 1, 64);
+  if (live) __builtin_nontemporal_store(total, out + (int64_t)level * sl + i * sr + xc * sf);
+}
+
 template <int D, int F>
 __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(
     const LevelTab tab, const Sched sched, const uint32_t level_mask, const float* __restrict__ x,
@@ -160,11 +196,11 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(
   }
 }
 
-Sched make_sched(int n_levels, int64_t n) {
+Sched make_sched(int n_levels, int64_t n, int coords_per_block = 256) {
   Sched s{};
   s.affinity = options().xcd_affinity;
   s.n_levels = n_levels;
-  s.chunks = (int)ceil_div(n, 256);
+  s.chunks = (int)ceil_div(n, coords_per_block);
   const int lpx = (n_levels + 7) / 8;
   s.virtual_levels = 8 * lpx;
   const int min_cnt = s.virtual_levels / n_levels;  // replicas of the least replicated level
@@ -182,6 +218,14 @@ struct FwdLaunch {
   static int run(const LevelTab& tab, const Sched& sched, const float* x, int64_t n,
                  const float* table, float* out, int64_t sl, int64_t sr, int64_t sf,
                  hipStream_t st) {
+    if constexpr (F == 2 && D >= 2) {
+      if (options().fwd_pair) {
+        const Sched ps = make_sched(sched.n_levels, n, 128);
+        hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<D>), dim3((unsigned)grid_blocks(ps)),
+                           dim3(256), 0, st, tab, ps, x, n, table, out, sl, sr, sf);
+        return check_launch("hashgrid_fwd_pair_kernel");
+      }
+    }
     hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F>), dim3((unsigned)grid_blocks(sched)), dim3(256),
                        0, st, tab, sched, x, n, table, out, sl, sr, sf);
     return check_launch("hashgrid_fwd_kernel");
