@@ -531,8 +531,15 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   float g_b1 = 0.f, g_b2 = 0.f, g_w3 = 0.f, g_b3 = 0.f, loss = 0.f;
 
   // x tile of a team: 32 features x 32 coordinates = 256 float4 pieces, one per thread
+  // interior tiles of a full-width, 16-byte aligned input (wave-uniform test, the usual case) take
+  // one unconditional load / four unconditional stores: the general path is ~100 branchy
+  // instructions per tile in a segment that no MFMA covers
+  const bool fast_io = a.k_in == KP && (a.n % 4) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
   auto load_x = [&](int64_t m0, int tid) {
     const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
+    if (fast_io && m0 + kTeamTile <= a.n)
+      return *reinterpret_cast<const float4*>(a.x + (int64_t)k * a.n + m0 + c4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < a.k_in && m0 + c4 < a.n) {
       const float* src = a.x + (int64_t)k * a.n + m0 + c4;
@@ -565,10 +572,16 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     if (dx_m0 < 0) return;
     const int l15 = lane & 15, lq = lane >> 4;
     const int64_t m = dx_m0 + dx_cb * 16 + l15;
+    if (a.k_in == KP && dx_m0 + kTeamTile <= a.n) {
+      float* dst = a.dx + (int64_t)(dx_kb * 16 + lq * 4) * a.n + m;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = dx_kb * 16 + lq * 4 + q;
-      if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[q];
+      for (int q = 0; q < 4; ++q) dst[(int64_t)q * a.n] = dx_pend[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = dx_kb * 16 + lq * 4 + q;
+        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[q];
+      }
     }
     dx_m0 = -1;
   };
