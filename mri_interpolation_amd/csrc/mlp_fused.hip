@@ -90,7 +90,7 @@ __host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + 
 // acc[ti][tj] += A(i, c) * B(j, c) over `steps` pairs of contraction indices, 32x32 tiles.
 // a / b point at this lane's element of tile (0,0) for contraction index 0; consecutive tiles are
 // a_tile / b_tile floats apart, consecutive contraction PAIRS a_step / b_step floats apart.
-template <int TI, int TJ>
+template <int TI, int TJ, bool PIN = true>
 __device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __restrict__ a,
                                        int a_tile, int a_step, const float* __restrict__ b,
                                        int b_tile, int b_step, int steps) {
@@ -124,13 +124,13 @@ __device__ __forceinline__ void mfma32(f32x16 (&acc)[TI][TJ], const float* __res
   int s = 0;
   for (; s + 2 * U <= steps; s += 2 * U) {
     fetch(1, s + U);
-    __builtin_amdgcn_sched_barrier(0);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
     compute(0);
-    __builtin_amdgcn_sched_barrier(0);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
     if (s + 2 * U < steps) fetch(0, s + 2 * U);
-    __builtin_amdgcn_sched_barrier(0);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
     compute(1);
-    __builtin_amdgcn_sched_barrier(0);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
   }
   if (s < steps) compute(0);  // steps = odd multiple of U
 }
@@ -466,6 +466,19 @@ __global__ __launch_bounds__(kThreads, 2) void tiny_mlp_kernel(const FusedArgs a
 constexpr int kTeamTile = 32;
 constexpr int kTeamThreads = 256;
 
+// Where the fetch-before-compute order of mfma32 is pinned with sched_barriers (measured per
+// segment): the short chains (layer 1, dW1: 16 MFMAs, where hipcc's own order exposes every
+// group's LDS latency) gain, the long ones (layer 2, dW2 + dz1) are 1 % faster left to hipcc.
+#ifndef PIN_S1
+#define PIN_S1 true
+#endif
+#ifndef PIN_S2
+#define PIN_S2 false
+#endif
+#ifndef PIN_S6
+#define PIN_S6 false
+#endif
+
 template <int H, int KP>
 struct TeamSmem {
   static constexpr int ldw2 = H + 1, ldw1 = KP + 1, lda = H + 1, ldx = KP + 1;
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     {
       f32x16 acc[1][1];
       zero(acc);
-      mfma32<1, 1>(acc, tm.xs + l31 * S::ldx + lh, 0, 2, sm.w1 + (w * 32 + l31) * S::ldw1 + lh,
+      mfma32<1, 1, PIN_S1>(acc, tm.xs + l31 * S::ldx + lh, 0, 2, sm.w1 + (w * 32 + l31) * S::ldw1 + lh,
                    0, 2, KP / 2);
       const int col = w * 32 + l31;
       const float bias = sm.b1[col];
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     {
       f32x16 acc[1][1];
       zero(acc);
-      mfma32<1, 1>(acc, tm.h1 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) * S::ldw2 + lh,
+      mfma32<1, 1, PIN_S2>(acc, tm.h1 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) * S::ldw2 + lh,
                    0, 2, H / 2);
       const int col = w * 32 + l31;
       const float bias = sm.b2[col];
@@ -690,11 +703,11 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
       __builtin_amdgcn_sched_barrier(0);  // keep the two running sums inside this segment
     }
     PROF_SYNC(6)  // S6: dW2 += dz2^T h1 ; dz1 = dz2 W2 (accumulators only)
-    mfma32<1, 4>(g_w2, tm.h2 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
+    mfma32<1, 4, PIN_S6>(g_w2, tm.h2 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
                  tm.h1 + l31 + lh * S::lda, 32, 2 * S::lda, kTeamTile / 2);
     f32x16 dz1[1][1];
     zero(dz1);
-    mfma32<1, 1>(dz1, tm.h2 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) + lh * S::ldw2, 0,
+    mfma32<1, 1, PIN_S6>(dz1, tm.h2 + l31 * S::lda + lh, 0, 2, sm.w2 + (w * 32 + l31) + lh * S::ldw2, 0,
                  2 * S::ldw2, H / 2);
     PROF_SYNC(7)  // S7: dz1 = (.) * (h1 > 0) over h1
     {

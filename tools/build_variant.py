@@ -12,7 +12,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("mri_interpolation_amd.build")
-out = os.path.join(ROOT, "tools", "libmri_variant.so")
+args = sys.argv[1:]
+name = "libmri_variant.so"
+if args and args[0].startswith("--name="):
+    name = args.pop(0)[len("--name="):]
+out = os.path.join(ROOT, "tools", name)
 srcs = [os.path.join(b.CSRC, s) for s in b.SOURCES]
-subprocess.check_call([b._hipcc()] + b.FLAGS + sys.argv[1:] + ["-shared", "-o", out] + srcs)
+subprocess.check_call([b._hipcc()] + b.FLAGS + args + ["-shared", "-o", out] + srcs)
 print(out)
