@@ -183,6 +183,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3  # time to QUEUE a step (host side)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
@@ -234,6 +235,7 @@ def main():
         "roofline": roof,
         "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
         "phases_sampled_every": max(1, args.phase_every),
+        "host_queue_ms_per_step": round(host_ms, 4),
         "final_loss": float(loss),
     }
     if step.encoder is not None:  # whole-step HBM fraction as north_star defines it
