@@ -774,8 +774,32 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     for (int q = 0; q < a.stagger; ++q) __syncthreads();
   __syncthreads();  // both teams are done with their activation images
 
-  // ---- one slab per team ------------------------------------------------------------------
-  float* slab = a.partial + ((int64_t)blockIdx.x * 2 + team) * slab_floats(H, a.k_in);
+  // ---- one slab per workgroup: team 1 hands its sums to team 0 through LDS (the weight images
+  //      are dead by now), team 0 adds its own on top and writes -- half the slab traffic of one
+  //      slab per team, and the order of the additions is fixed
+  float* x_w2 = sm.w2;  // [H][H] exchange images, plain leading dimensions
+  float* x_w1 = sm.w1;  // [H][KP]
+  if (team == 1) {
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        x_w2[(w * 32 + acc_row(q, lh)) * H + tj * 32 + l31] = g_w2[0][tj][q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x_w1[(w * 32 + acc_row(q, lh)) * KP + l31] = g_w1[0][0][q];
+  }
+  float* red = sm.team[0].h2;   // scratch shared by both teams below: [2 teams][3][256] + tail
+  float* red1 = sm.team[1].h2;
+  (team == 0 ? red : red1)[tid] = g_b1;
+  (team == 0 ? red : red1)[kTeamThreads + tid] = g_b2;
+  (team == 0 ? red : red1)[2 * kTeamThreads + tid] = g_w3;
+  if (tid < kTeamTile) {
+    (team == 0 ? red : red1)[3 * kTeamThreads + tid] = g_b3;
+    (team == 0 ? red : red1)[3 * kTeamThreads + kTeamTile + tid] = loss;
+  }
+  __syncthreads();
+  if (team != 0) return;
+  float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
   float* p_w1 = slab;
   float* p_b1 = p_w1 + H * a.k_in;
   float* p_w2 = p_b1 + H;
@@ -785,34 +809,33 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      p_w2[(w * 32 + acc_row(q, lh)) * H + tj * 32 + l31] = g_w2[0][tj][q];
+    for (int q = 0; q < 16; ++q) {
+      const int e = (w * 32 + acc_row(q, lh)) * H + tj * 32 + l31;
+      p_w2[e] = g_w2[0][tj][q] + x_w2[e];
+    }
 #pragma unroll
-  for (int q = 0; q < 16; ++q)
-    if (l31 < a.k_in) p_w1[(w * 32 + acc_row(q, lh)) * a.k_in + l31] = g_w1[0][0][q];
-  float* red = tm.h2;  // scratch (team private)
-  red[tid] = g_b1;
-  __syncthreads();
-  if (tid < H) p_b1[tid] = red[(tid / 32) * 64 + (tid & 31)] + red[(tid / 32) * 64 + 32 + (tid & 31)];
-  __syncthreads();
-  red[tid] = g_b2;
-  red[kTeamThreads + tid] = g_w3;
-  __syncthreads();
+  for (int q = 0; q < 16; ++q) {
+    const int r = w * 32 + acc_row(q, lh);
+    if (l31 < a.k_in) p_w1[r * a.k_in + l31] = g_w1[0][0][q] + x_w1[r * KP + l31];
+  }
+  // per-column sums live in two threads per team (the two 16-coordinate halves of the dz2 / mask
+  // passes for b2 / w3, the two lane halves of the accumulator layout for b1)
   if (tid < H) {
-    p_b2[tid] = red[tid] + red[H + tid];
-    p_w3[tid] = red[kTeamThreads + tid] + red[kTeamThreads + H + tid];
+    const int i1 = (tid / 32) * 64 + (tid & 31);
+    p_b1[tid] = (red[i1] + red[i1 + 32]) + (red1[i1] + red1[i1 + 32]);
+    p_b2[tid] = (red[kTeamThreads + tid] + red[kTeamThreads + H + tid]) +
+                (red1[kTeamThreads + tid] + red1[kTeamThreads + H + tid]);
+    p_w3[tid] = (red[2 * kTeamThreads + tid] + red[2 * kTeamThreads + H + tid]) +
+                (red1[2 * kTeamThreads + tid] + red1[2 * kTeamThreads + H + tid]);
   }
-  __syncthreads();
-  if (tid < kTeamTile) {
-    red[tid] = g_b3;
-    red[kTeamTile + tid] = loss;
-  }
-  __syncthreads();
   if (tid == 0) {
     float sb = 0.f, sl = 0.f;
-    for (int c = 0; c < kTeamTile; ++c) {
-      sb += red[c];
-      sl += red[kTeamTile + c];
+    for (int t = 0; t < 2; ++t) {
+      const float* rr = t == 0 ? red : red1;
+      for (int c = 0; c < kTeamTile; ++c) {
+        sb += rr[3 * kTeamThreads + c];
+        sl += rr[3 * kTeamThreads + kTeamTile + c];
+      }
     }
     p_b3[0] = sb;
     p_b3[1] = sl * a.inv_n;
@@ -876,7 +899,7 @@ int pick_blocks(int hidden, int64_t n) {
   return (int)std::min<int64_t>(ceil_div(n, kTile), 512);  // 52-75 KiB of LDS: two per CU
 }
 
-int slab_count(int hidden, int blocks) { return hidden == 128 ? 2 * blocks : blocks; }
+int slab_count(int hidden, int blocks) { (void)hidden; return blocks; }  // one slab per workgroup
 
 bool supported(int k_in, int hidden, int dim_out) {
   if (dim_out != 1 || k_in < 1) return false;
