@@ -374,11 +374,15 @@ __global__ __launch_bounds__(kThreads, 2) void tiny_mlp_kernel(const FusedArgs a
         const int tile = wave + 4 * u;
         const int kb = tile / (kTile / 16), cb = tile % (kTile / 16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* pa = sm.w1 + lq * S::ldw1 + kb * 16 + l15;          // A(i = k, kk = o)
-        const float* pb = sm.h1 + (cb * 16 + l15) * S::lda + lq;         // B(kk = o, j = c)
+        // lane group lq takes hidden units 8 lq + j + 32 m (step = 8 m + j): two lanes per LDS
+        // bank instead of four (see the team kernel)
+        const float* pa = sm.w1 + 8 * lq * S::ldw1 + kb * 16 + l15;      // A(i = k, kk = o)
+        const float* pb = sm.h1 + (cb * 16 + l15) * S::lda + 8 * lq;     // B(kk = o, j = c)
 #pragma unroll 8
-        for (int s = 0; s < H / 4; ++s)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s * 4 * S::ldw1], pb[s * 4], acc, 0, 0, 0);
+        for (int s = 0; s < H / 4; ++s) {
+          const int o = 32 * (s / 8) + s % 8;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[o * S::ldw1], pb[o], acc, 0, 0, 0);
+        }
         dx_pend[u] = acc;
       }
       dx_m0 = m0;
@@ -722,42 +726,54 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     }
     PROF_SYNC(8)  // S8: dW1 += dz1^T x ; dx^T = W1^T dz1^T
     if (a.dx) {
-      // one wave per SIMD works here (the other team sits in a short segment), so nothing but
-      // this wave's own pipelining hides the LDS latency: the first dx group is fetched before
-      // dW1's MFMAs, every later group before the MFMAs of the group in front of it
-      constexpr int U = 4;
+      // One wave per SIMD works here (the other team sits in a short segment), so nothing but this
+      // wave's own instruction stream hides latencies.  dW1 (16 steps of 32x32x2) and dx^T (32
+      // steps of 16x16x4) are two independent accumulator chains: they are interleaved 1 : 2, in
+      // groups of WU + 2 WU steps whose fragments are fetched one group ahead.
+      constexpr int WU = 2, GROUPS = (kTeamTile / 2) / WU;
+      static_assert(GROUPS * 2 * WU == H / 4 && GROUPS % 2 == 0, "dW1 : dx steps are 1 : 2");
       const int l15 = lane & 15, lq = lane >> 4;
-      const float* pa = sm.w1 + lq * S::ldw1 + dx_kb * 16 + l15;
-      const float* pb = tm.h1 + (dx_cb * 16 + l15) * S::lda + lq;
-      float xa[2][U], xb[2][U];
+      // dx^T: the four lane groups of a 16x16x4 step take hidden units 8 lq + j + 32 m (step =
+      // 8 m + j) instead of 4 step + lq: with the odd leading dimensions the (l15, lq) lanes then
+      // fall on banks l15 + 8 lq, two lanes per bank (the floor for 64 lanes) instead of four
+      const float* pa = sm.w1 + 8 * lq * S::ldw1 + dx_kb * 16 + l15;
+      const float* pb = tm.h1 + (dx_cb * 16 + l15) * S::lda + 8 * lq;
+      const float* wa_p = tm.h1 + (w * 32 + l31) + lh * S::lda;   // dz1^T, step stride 2 lda
+      const float* wb_p = tm.xs + l31 + lh * S::ldx;              // x^T,   step stride 2 ldx
+      float wa[2][WU], wb[2][WU], xa[2][2 * WU], xb[2][2 * WU];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      auto fetch = [&](int buf, int s0) {
+      auto fetch = [&](int buf, int g) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          xa[buf][u] = pa[(s0 + u) * 4 * S::ldw1];
-          xb[buf][u] = pb[(s0 + u) * 4];
+        for (int u = 0; u < WU; ++u) {
+          wa[buf][u] = wa_p[(g * WU + u) * 2 * S::lda];
+          wb[buf][u] = wb_p[(g * WU + u) * 2 * S::ldx];
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * WU; ++u) {
+          const int st = g * 2 * WU + u, o = 32 * (st / 8) + st % 8;
+          xa[buf][u] = pa[o * S::ldw1];
+          xb[buf][u] = pb[o];
         }
       };
       auto compute = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[buf][u], xb[buf][u], acc, 0, 0, 0);
+        for (int u = 0; u < WU; ++u) {
+          g_w1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[buf][u], wb[buf][u], g_w1[0][0], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[buf][2 * u], xb[buf][2 * u], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[buf][2 * u + 1], xb[buf][2 * u + 1], acc, 0, 0, 0);
+        }
       };
-      static_assert((H / 4) % (2 * U) == 0, "dx steps come in pairs of groups");
       fetch(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma32<1, 1>(g_w1, tm.h1 + (w * 32 + l31) + lh * S::lda, 0, 2 * S::lda,
-                   tm.xs + l31 + lh * S::ldx, 0, 2 * S::ldx, kTeamTile / 2);
 #pragma unroll
-      for (int st = 0; st < H / 4; st += 2 * U) {
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(1, st + U);
+      for (int g = 0; g < GROUPS; g += 2) {
+        fetch(1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 * U < H / 4) fetch(0, st + 2 * U);
+        if (g + 2 < GROUPS) fetch(0, g + 2);
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       dx_pend = acc;
       dx_m0 = m0;
