@@ -32,6 +32,10 @@ WORKLOADS = {
                  lr=5e-3, norm_siren=False),
     "cfg3": dict(shape=(256, 256, 256), model="siren", hidden=256, batch=1 << 20, lr=1e-4,
                  norm_siren=True),
+    # BASELINE config 5's shape and encoder (4-D: 16 corners per level) on a synthetic x,y,z,t
+    # phantom -- the sample volume does not travel to the GPU box; all frames are trained on
+    "cfg5": dict(shape=(352, 352, 6, 15), model="hash", finest=16 * 1.4 ** 15, hidden=128,
+                 batch=1 << 18, lr=5e-3, norm_siren=False),
 }
 
 
@@ -40,7 +44,7 @@ def build_model(w):
     from mri_interpolation_amd import models
     torch.manual_seed(1337)  # reference launcher.py:30
     if w["model"] == "hash":
-        return models.HashMLP(dim_in=3, n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+        return models.HashMLP(dim_in=len(w["shape"]), n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
                               base_resolution=16, finest_resolution=w["finest"],
                               dim_hidden=w["hidden"], dim_out=1, n_layers=3,
                               activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
@@ -85,13 +89,14 @@ def cpu_baseline(w, name):
     cores = int(os.environ.get("MRI_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     b = 1 << 15 if w["model"] == "hash" else 1 << 14
+    dim = len(w["shape"])
     if w["model"] == "hash":
-        m = otrain.HashMlpModel(3, 16, 2, 19, 16, w["finest"], hidden=[w["hidden"]] * 2, seed=1)
+        m = otrain.HashMlpModel(dim, 16, 2, 19, 16, w["finest"], hidden=[w["hidden"]] * 2, seed=1)
     else:
-        m = otrain.SirenModel(3, w["hidden"], 1, 5, seed=1)
+        m = otrain.SirenModel(dim, w["hidden"], 1, 5, seed=1)
     g = torch.Generator().manual_seed(0)
     lo = -1.0 if w["norm_siren"] else 0.0
-    batches = [(torch.rand(b, 3, generator=g) * (1 - lo) + lo, torch.rand(b, 1, generator=g))
+    batches = [(torch.rand(b, dim, generator=g) * (1 - lo) + lo, torch.rand(b, 1, generator=g))
                for _ in range(2)]
     opt = None
     _, opt = otrain.train_steps(m, batches[:1], w["lr"], opt)  # warm-up

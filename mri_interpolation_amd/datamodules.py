@@ -39,15 +39,31 @@ PHANTOM_BLOBS = (
 
 
 def phantom_volume(shape: Sequence[int], device="cuda") -> torch.Tensor:
-    """Analytic 3-D test volume (12 Gaussian blobs + a sinusoid), min-max normalised to
-    [0, 1] float32, evaluated at linspace(0,1,s) voxel centres in float64 on `device`."""
+    """Analytic test volume (12 Gaussian blobs + a sinusoid), min-max normalised to [0, 1]
+    float32, evaluated at linspace(0,1,s) voxel centres in float64 on `device`.  3-D shapes give
+    the phantom of SURVEY.md 8(d); a 4-D shape (x, y, z, t) adds time: the blobs drift along x
+    and breathe in amplitude, frame by frame (a stand-in for the dynamic sample volume)."""
+    if len(shape) == 4:
+        frames = []
+        for t in torch.linspace(0.0, 1.0, shape[3], dtype=torch.float64).tolist():
+            frames.append(_phantom_frame(shape[:3], device, t))
+        v = torch.stack(frames, dim=-1)
+    else:
+        v = _phantom_frame(shape, device, None)
+    v = (v - v.min()) / (v.max() - v.min())
+    return v.to(torch.float32)
+
+
+def _phantom_frame(shape, device, t):
     ax = [torch.linspace(0.0, 1.0, s, dtype=torch.float64, device=device) for s in shape]
     x, y, z = torch.meshgrid(*ax, indexing="ij")
     v = 0.05 * torch.sin(2.0 * math.pi * (7.0 * x + 11.0 * y + 13.0 * z))
-    for a, cx, cy, cz, s in PHANTOM_BLOBS:
+    for m, (a, cx, cy, cz, s) in enumerate(PHANTOM_BLOBS):
+        if t is not None:
+            cx = cx + 0.08 * math.sin(2.0 * math.pi * (t + m / 12.0))
+            a = a * (1.0 + 0.25 * math.cos(2.0 * math.pi * (t + m / 7.0)))
         v = v + a * torch.exp(-((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) / (2.0 * s * s))
-    v = (v - v.min()) / (v.max() - v.min())
-    return v.to(torch.float32)
+    return v
 
 
 class MriImage:

@@ -152,3 +152,17 @@ def test_interp_baseline_is_linear_in_time():
     np.testing.assert_array_equal(out2[..., ::2], data2[..., ::2])
     np.testing.assert_allclose(out2[..., 1], 0.5 * (data2[..., 0] + data2[..., 2]))
     np.testing.assert_array_equal(out2[..., 7], data2[..., 6])  # beyond the last even frame
+
+
+def test_phantom_4d_is_a_moving_3d_phantom():
+    """phantom_volume with an (x, y, z, t) shape: normalised to [0, 1], frames differ, and a
+    3-D shape still gives the static phantom of SURVEY.md 8(d)."""
+    import torch
+    from mri_interpolation_amd.datamodules import phantom_volume
+    v4 = phantom_volume((12, 10, 6, 5), device="cpu")
+    assert v4.shape == (12, 10, 6, 5) and v4.dtype == torch.float32
+    assert float(v4.min()) == 0.0 and float(v4.max()) == 1.0
+    assert not torch.allclose(v4[..., 0], v4[..., 2])
+    v3 = phantom_volume((12, 10, 6), device="cpu")
+    assert v3.shape == (12, 10, 6) and float(v3.min()) == 0.0 and float(v3.max()) == 1.0
+
