@@ -172,6 +172,23 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const TileRe
   }
 }
 
+// Phase timing for tools/gemm_phases.py (a tools-only build with -DMRI_GEMM_PROFILE; nothing in the
+// shipped library): shader-clock cycles per wave, summed over the chunks of its tile.
+#ifdef MRI_GEMM_PROFILE
+__device__ long long* g_gemm_profile = nullptr;
+#define GP_BEGIN long long gp_t = clock64(); long long gp_acc[8] = {};
+#define GP_MARK(i) { const long long gp_n = clock64(); gp_acc[i] += gp_n - gp_t; gp_t = gp_n; }
+#define GP_END                                                                              \
+  if (g_gemm_profile && (threadIdx.x & 63) == 0) {                                          \
+    long long* dst = g_gemm_profile + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;   \
+    for (int q = 0; q < 8; ++q) dst[q] = gp_acc[q];                                         \
+  }
+#else
+#define GP_BEGIN
+#define GP_MARK(i)
+#define GP_END
+#endif
+
 template <int WI, int WJ, int TI, int TJ, int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int BI = WI * TI * 32, BJ = WJ * TJ * 32;
@@ -225,6 +242,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
   float rowsum = 0.f;
   const bool want_rowsum = EPI == EPI_ATOMIC && a.rowsum_out != nullptr && tj_blk == 0;
 
+  GP_BEGIN
   TileRegs<BI> pr;
   TileRegs<BJ> qr;
   if (c_begin < c_end) {
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
     store_tile<BJ>(lds + TileImage<BI>::kFloats, qr, a.q.mode);
   }
   __syncthreads();
+  GP_MARK(0)  // prologue: first chunk load + store + barrier
   int stage_id = 0;
   for (int64_t c0 = c_begin; c0 < c_end; c0 += KB) {
     const float* __restrict__ cur = lds + stage_id * kStage;
@@ -243,6 +262,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
       load_tile<BI>(pr, a.p, i0, a.I, c0 + KB, c_end);
       load_tile<BJ>(qr, a.q, j0, a.J, c0 + KB, c_end);
     }
+    GP_MARK(1)  // issue of the next chunk's global loads
     const float* __restrict__ pf = cur + pf_off;
     const float* __restrict__ qf = cur + qf_off;
     const int kc = (int)min((int64_t)KB, c_end - c0);
@@ -289,11 +309,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
       compute(pa0, qb0, pairs - 2 * U);
       compute(pa1, qb1, pairs - 3 * U);
     }
+    GP_MARK(2)  // fragment reads + MFMAs of this chunk
     if (more) {
       store_tile<BI>(nxt, pr, a.p.mode);
       store_tile<BJ>(nxt + TileImage<BI>::kFloats, qr, a.q.mode);
     }
+    GP_MARK(3)  // wait for the loads, store them to the other stage
     __syncthreads();  // next stage complete, and everyone is done reading the current one
+    GP_MARK(4)  // barrier
     stage_id ^= 1;
   }
 
@@ -362,12 +385,94 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
       }
     }
   };
-  if (i0 + BI <= a.I && j0 + BJ <= a.J)
-    emit(std::false_type{});
-  else
-    emit(std::true_type{});
+  // Forward tiles inside the output whose rows can be written 16 bytes at a time go through LDS
+  // (free by now): the accumulator layout gives each lane single floats of 32-wide row pieces,
+  // i.e. BI*BJ/256 four-byte store instructions per thread; staged, a thread writes float4s and
+  // a wave 512-byte runs of a row.  The per-float stores were 27 % (ReLU) / 43 % (sine) of a
+  // wave's time in a 256 x 256 layer (tools/gemm_phases.py).
+  constexpr int kOutLd = BJ + 4;
+  constexpr bool kCanStage = BI * kOutLd <= 2 * kStage && BJ % 4 == 0 && (BI * BJ / 4) % kThreads == 0;
+  const bool inside = i0 + BI <= a.I && j0 + BJ <= a.J;
+  bool staged = false;
+  if constexpr (EPI == EPI_FORWARD && kCanStage) {
+    const bool vec_ok = a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                        (!a.deriv_out || (a.ldd_out % 4 == 0 &&
+                                          (reinterpret_cast<uintptr_t>(a.deriv_out) & 15) == 0));
+    if (inside && vec_ok) {
+      staged = true;
+      float dv[TI][TJ][16];  // derivative, kept while the activation is on its way out
+      auto stage = [&](auto&& value_of) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (wi * TI + ti) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+              lds[row * kOutLd + (wj * TJ + tj) * 32 + l31] = value_of(ti, tj, r);
+            }
+      };
+      auto flush = [&](float* __restrict__ dst, int64_t ld) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < BI * BJ / 4 / kThreads; ++q) {
+          const int v = threadIdx.x + q * kThreads;
+          const int row = v / (BJ / 4), c4 = (v % (BJ / 4)) * 4;
+          const f4v x = *reinterpret_cast<const f4v*>(lds + row * kOutLd + c4);
+          *reinterpret_cast<f4v*>(dst + (i0 + row) * ld + j0 + c4) = x;
+        }
+      };
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const float bj = a.bias ? a.bias[j0 + (wj * TJ + tj) * 32 + l31] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[ti][tj][r] + bj, d = 1.0f;
+            switch (a.act) {
+              case MRI_ACT_RELU:
+                v = fmaxf(v, 0.f);
+                break;
+              case MRI_ACT_SINE: {
+                float sn, cs;
+                sincos_fast(a.w0 * v, &sn, &cs);
+                v = sn;
+                d = a.w0 * cs;
+              } break;
+              case MRI_ACT_GELU:
+                d = gelu_grad_f(v);
+                v = gelu_f(v);
+                break;
+              default:
+                break;
+            }
+            acc[ti][tj][r] = v;
+            dv[ti][tj][r] = d;
+          }
+        }
+      __syncthreads();  // every wave is done with the operand stages
+      stage([&](int ti, int tj, int r) { return acc[ti][tj][r]; });
+      __syncthreads();
+      flush(a.out, a.ldo);
+      if (a.deriv_out) {
+        __syncthreads();
+        stage([&](int ti, int tj, int r) { return dv[ti][tj][r]; });
+        __syncthreads();
+        flush(a.deriv_out, a.ldd_out);
+      }
+    }
+  }
+  if (!staged) {
+    if (inside)
+      emit(std::false_type{});
+    else
+      emit(std::true_type{});
+  }
   if (want_rowsum && threadIdx.x < BI && i0 + threadIdx.x < a.I)
     atomicAdd(a.rowsum_out + i0 + threadIdx.x, rowsum);
+  GP_MARK(5)  // epilogue
+  GP_END
 }
 
 // elementwise dy *= g
@@ -524,3 +629,13 @@ extern "C" int mri_apply_deriv(float* dy, int64_t lddy, int32_t deriv_mode, cons
                      (hipStream_t)stream, dy, lddy, deriv_mode, deriv, ldd, m, (int)n);
   return check_launch("apply_deriv_kernel");
 }
+
+#ifdef MRI_GEMM_PROFILE
+extern "C" int mri_debug_set_gemm_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mri::g_gemm_profile), &device_buffer, sizeof(device_buffer)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#endif
+
