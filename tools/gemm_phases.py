@@ -87,6 +87,28 @@ def main():
     print(f"backward-data (x derivative): {ms:.3f} ms, {2.0 * m * n * k / ms / 1e9:.1f} TF; {tot:.0f} cycles")
     for i, nm in enumerate(names):
         print(f"   {nm:12s} {float(mean[i]):8.0f}  ({100 * float(mean[i]) / tot:4.1f} %)")
+    # backward-weight: dW += dy^T x (batch contraction, split over workgroups)
+    dw = torch.zeros(n, k, device="cuda")
+    db = torch.zeros(n, device="cuda")
+    args = [P(dy.data_ptr()), C.c_int64(n), P(x.data_ptr()), C.c_int64(k), C.c_int64(1), C.c_int64(m),
+            C.c_int32(n), C.c_int32(k), P(dw.data_ptr()), P(db.data_ptr()), P(None)]
+    for _ in range(2):
+        assert lib.mri_linear_backward_weight(*args) == 0
+    torch.cuda.synchronize()
+    prof.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.mri_linear_backward_weight(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    p = prof.cpu().reshape(-1, 8).double()
+    p = p[p.sum(1) > 0]
+    mean = p.mean(0)
+    tot = float(mean[:6].sum())
+    print(f"backward-weight: {ms:.3f} ms, {2.0 * m * n * k / ms / 1e9:.1f} TF; {p.shape[0]} waves, {tot:.0f} cycles each")
+    for i, nm in enumerate(names):
+        print(f"   {nm:12s} {float(mean[i]):8.0f}  ({100 * float(mean[i]) / tot:4.1f} %)")
 
 
 if __name__ == "__main__":
