@@ -125,6 +125,9 @@ def main():
                     help="bracket the phases with HIP events on every n-th timed step only: "
                          "an event pair stalls the queue ~15 us, 5 pairs per step cost 8 %%")
     ap.add_argument("--bwd-method", type=int, default=0)
+    ap.add_argument("--split", type=float, default=None,
+                    help="fraction of the batch in the first slice of the fused decoder step "
+                         "(0 = one slice); default: FusedStep's")
     ap.add_argument("--opt", action="append", default=[],
                     help="library tuning option name=value (mri_set_option), repeatable")
     ap.add_argument("--grad-buckets", type=int, default=0,
@@ -157,6 +160,8 @@ def main():
     step.bwd_method = args.bwd_method
     if args.grad_buckets:
         step.grad_buckets = args.grad_buckets
+    if args.split is not None:
+        step.split_fraction = args.split
     n_params = sum(p.numel() for p in model.parameters())
     counter = [0]
     events = {}

@@ -210,6 +210,19 @@ int mri_tiny_mlp_train_overwrite(const float* x, const float* target, int64_t n,
                                  float* loss_out, float* y, void* workspace,
                                  int64_t workspace_bytes, void* stream);
 
+/* The same step for a SLICE of a batch: columns [0, n) of feature-major blocks x / d_x whose feature
+ * rows are x_ld elements apart (x_ld >= n), `n` targets, out of a batch of n_total coordinates --
+ * the mean of the loss and the gradient scale are taken over n_total, so the slices of a batch
+ * add up to the whole-batch call (first slice with overwrite = 1, the others with 0).  Lets a
+ * caller run the encoder of slice k+1 beside the decoder of slice k. */
+int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, int64_t n,
+                             int64_t n_total, int32_t k_in, int32_t hidden, const float* w1,
+                             const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                             float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                             float* loss_out, float* y, int32_t overwrite, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* ---- loss ------------------------------------------------------------------------------
  * F.mse_loss(y, y_pred) (reference models.py:64): loss_out[0] += mean((pred-target)^2)
  * (device scalar, caller zeroes), d_pred = 2 (pred - target) / (count * grad_divisor) if

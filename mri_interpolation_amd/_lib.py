@@ -57,6 +57,8 @@ SIGNATURES = {
     "mri_frequency_backward": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I64, _P],
     "mri_mse_loss": [_P, _P, _I64, _F, _P, _P, _P],
     "mri_tiny_mlp_forward": [_P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mri_tiny_mlp_train_slice": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _P],
     "mri_tiny_mlp_train": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                            _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_tiny_mlp_train_overwrite": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,

@@ -44,6 +44,7 @@ struct FusedArgs {
   float* dx;           // (k_in, n) feature-major, optional
   float* partial;      // [gridDim.x][slab] partial gradients + loss
   int64_t n;
+  int64_t ld;          // leading dimension of x and dx (elements between feature rows), >= n
   int k_in;
   float grad_scale;    // 2 / (n * grad_divisor)
   int stagger;         // team kernel: segments team 1 runs behind team 0
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 2) void tiny_mlp_kernel(const FusedArgs a
       const int k = e / (kTile / 4), c4 = (e % (kTile / 4)) * 4;
       v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k < a.k_in && m0 + c4 < a.n) {
-        const float* src = a.x + (int64_t)k * a.n + m0 + c4;
+        const float* src = a.x + (int64_t)k * a.ld + m0 + c4;
         if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
           v[j] = *reinterpret_cast<const float4*>(src);
         } else {
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kThreads, 2) void tiny_mlp_kernel(const FusedArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kb * 16 + lq * 4 + r;
-        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[u][r];
+        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.ld + m] = dx_pend[u][r];
       }
     }
     dx_m0 = -1;
@@ -551,15 +552,15 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   // interior tiles of a full-width, 16-byte aligned input (wave-uniform test, the usual case) take
   // one unconditional load / four unconditional stores: the general path is ~100 branchy
   // instructions per tile in a segment that no MFMA covers
-  const bool fast_io = a.k_in == KP && (a.n % 4) == 0 &&
+  const bool fast_io = a.k_in == KP && (a.ld % 4) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
   auto load_x = [&](int64_t m0, int tid) {
     const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
     if (fast_io && m0 + kTeamTile <= a.n)
-      return *reinterpret_cast<const float4*>(a.x + (int64_t)k * a.n + m0 + c4);
+      return *reinterpret_cast<const float4*>(a.x + (int64_t)k * a.ld + m0 + c4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < a.k_in && m0 + c4 < a.n) {
-      const float* src = a.x + (int64_t)k * a.n + m0 + c4;
+      const float* src = a.x + (int64_t)k * a.ld + m0 + c4;
       if (m0 + c4 + 3 < a.n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
         v = *reinterpret_cast<const float4*>(src);
       } else {
@@ -590,14 +591,14 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     const int l15 = lane & 15, lq = lane >> 4;
     const int64_t m = dx_m0 + dx_cb * 16 + l15;
     if (a.k_in == KP && dx_m0 + kTeamTile <= a.n) {
-      float* dst = a.dx + (int64_t)(dx_kb * 16 + lq * 4) * a.n + m;
+      float* dst = a.dx + (int64_t)(dx_kb * 16 + lq * 4) * a.ld + m;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[(int64_t)q * a.n] = dx_pend[q];
+      for (int q = 0; q < 4; ++q) dst[(int64_t)q * a.ld] = dx_pend[q];
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = dx_kb * 16 + lq * 4 + q;
-        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.n + m] = dx_pend[q];
+        if (k < a.k_in && m < a.n) a.dx[(int64_t)k * a.ld + m] = dx_pend[q];
       }
     }
     dx_m0 = -1;
@@ -964,11 +965,11 @@ extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int
   MRI_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && y, "NULL device pointer");
   FusedArgs a{};
   a.x = x, a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3, a.y = y;
-  a.n = n, a.k_in = k_in;
+  a.n = n, a.ld = n, a.k_in = k_in;
   return dispatch(a, hidden, false, pick_blocks(hidden, n), (hipStream_t)stream);
 }
 
-static int tiny_mlp_train_impl(int overwrite, const float* x, const float* target, int64_t n, int32_t k_in,
+static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const float* x, const float* target, int64_t n, int32_t k_in,
                                   int32_t hidden, const float* w1, const float* b1,
                                   const float* w2, const float* b2, const float* w3,
                                   const float* b3, float grad_divisor, float* d_w1, float* d_b1,
@@ -978,6 +979,8 @@ static int tiny_mlp_train_impl(int overwrite, const float* x, const float* targe
   MRI_REQUIRE(supported(k_in, hidden, 1), "tiny MLP %d -> %d -> %d -> 1 is not supported", k_in,
               hidden, hidden);
   MRI_REQUIRE(n >= 0 && grad_divisor > 0.f, "bad n / grad_divisor");
+  MRI_REQUIRE(ld >= n && n_total >= n, "slice of %lld columns in a block of %lld, batch of %lld",
+              (long long)n, (long long)ld, (long long)n_total);
   if (n == 0) return MRI_OK;
   MRI_REQUIRE(x && target && w1 && b1 && w2 && b2 && w3 && b3, "NULL device pointer");
   MRI_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && loss_out, "NULL gradient pointer");
@@ -991,9 +994,9 @@ static int tiny_mlp_train_impl(int overwrite, const float* x, const float* targe
   a.x = x, a.target = target;
   a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3;
   a.y = y, a.dx = d_x, a.partial = static_cast<float*>(workspace);
-  a.n = n, a.k_in = k_in;
-  a.grad_scale = (float)(2.0 / ((double)n * (double)grad_divisor));
-  a.inv_n = (float)(1.0 / (double)n);
+  a.n = n, a.ld = ld, a.k_in = k_in;
+  a.grad_scale = (float)(2.0 / ((double)n_total * (double)grad_divisor));
+  a.inv_n = (float)(1.0 / (double)n_total);
   a.stagger = std::min(std::max(options().mlp_stagger, 0), 8);
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
@@ -1017,7 +1020,7 @@ extern "C" int mri_tiny_mlp_train(const float* x, const float* target, int64_t n
                                   float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
                                   float* loss_out, float* y, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
-  return tiny_mlp_train_impl(0, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
+  return tiny_mlp_train_impl(0, n, n, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
                              d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
                              workspace_bytes, stream);
 }
@@ -1030,9 +1033,22 @@ extern "C" int mri_tiny_mlp_train_overwrite(const float* x, const float* target,
                                             float* d_w3, float* d_b3, float* d_x, float* loss_out,
                                             float* y, void* workspace, int64_t workspace_bytes,
                                             void* stream) {
-  return tiny_mlp_train_impl(1, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
+  return tiny_mlp_train_impl(1, n, n, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3, grad_divisor,
                              d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
                              workspace_bytes, stream);
+}
+
+extern "C" int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, int64_t n,
+                                        int64_t n_total, int32_t k_in, int32_t hidden,
+                                        const float* w1, const float* b1, const float* w2,
+                                        const float* b2, const float* w3, const float* b3,
+                                        float grad_divisor, float* d_w1, float* d_b1, float* d_w2,
+                                        float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                        float* loss_out, float* y, int32_t overwrite,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+  return tiny_mlp_train_impl(overwrite ? 1 : 0, x_ld, n_total, x, target, n, k_in, hidden, w1, b1,
+                             w2, b2, w3, b3, grad_divisor, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x,
+                             loss_out, y, workspace, workspace_bytes, stream);
 }
 
 #ifdef MRI_MLP_PROFILE

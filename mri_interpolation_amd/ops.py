@@ -74,7 +74,11 @@ def _enc_strides(desc: GridDesc, n: int, feature_major: bool):
 
 # --------------------------------------------------------------------------- hash grid
 def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
-                     out: Optional[torch.Tensor] = None, feature_major: bool = False):
+                     out: Optional[torch.Tensor] = None, feature_major: bool = False,
+                     row_offset: int = 0):
+    """Encode the rows of `x`.  With `row_offset`, `x` is a slice of a larger batch whose features
+    live in `out` (the whole batch's buffer): the slice's features go to rows / columns
+    [row_offset, row_offset + len(x))."""
     _gpu(x, table, out)
     x = _rowmajor(x).contiguous()
     n, width = x.shape[0], desc.n_levels * desc.n_features
@@ -83,9 +87,13 @@ def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
     if out is None:
         out = torch.empty((width, n) if feature_major else (n, width), device=x.device,
                           dtype=torch.float32)
-    sl, sr, sf = _enc_strides(desc, n, feature_major)
-    _lib.call("mri_hashgrid_forward", C.byref(desc), _ptr(x), n, _ptr(table), _ptr(out), sl, sr,
-              sf, _stream())
+    n_total = out.shape[1] if feature_major else out.shape[0]
+    if row_offset < 0 or row_offset + n > n_total:
+        raise ValueError("slice does not fit the output buffer")
+    sl, sr, sf = _enc_strides(desc, n_total, feature_major)
+    base = out.data_ptr() + 4 * row_offset * sr
+    _lib.call("mri_hashgrid_forward", C.byref(desc), _ptr(x), n, _ptr(table), C.c_void_p(base), sl,
+              sr, sf, _stream())
     return out
 
 
@@ -378,6 +386,27 @@ def tiny_mlp_train(x_fm, target, params, grads, loss_out, d_x=None, y=None,
               _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor), _ptr(g1),
               _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3), _ptr(d_x), _ptr(loss_out),
               _ptr(y), _ptr(ws), ws.numel() * 4, _stream())
+    return loss_out
+
+
+def tiny_mlp_train_slice(x_fm, target, col_offset: int, n: int, params, grads, loss_out, d_x,
+                         grad_divisor: float = 1.0, overwrite: bool = False):
+    """tiny_mlp_train for columns [col_offset, col_offset + n) of the feature-major batch block
+    x_fm (k_in, n_total) and of d_x; the loss mean and gradient scale are those of the whole
+    batch, so the slices of a batch add up to the whole-batch call."""
+    (w1, b1), (w2, b2), (w3, b3) = params
+    (g1, gb1), (g2, gb2), (g3, gb3) = grads
+    _gpu(x_fm, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_x)
+    k_in, n_total = x_fm.shape
+    if col_offset < 0 or col_offset + n > n_total or target.numel() != n_total:
+        raise ValueError("slice does not fit the batch")
+    ws = _tiny_workspace(k_in, w1.shape[0], n, x_fm.device)
+    at = lambda t: C.c_void_p(t.data_ptr() + 4 * col_offset)  # noqa: E731
+    _lib.call("mri_tiny_mlp_train_slice", at(x_fm), n_total, at(target), n, n_total, k_in,
+              w1.shape[0], _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3),
+              float(grad_divisor), _ptr(g1), _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3),
+              at(d_x) if d_x is not None else None, _ptr(loss_out), None, 1 if overwrite else 0,
+              _ptr(ws), ws.numel() * 4, _stream())
     return loss_out
 
 

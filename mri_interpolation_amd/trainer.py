@@ -93,6 +93,14 @@ class FusedStep:
         self.overlap_count = True
         self._side = None
         self._counted = False
+        # Fused decoder, optional: cut the batch in two slices and run the encoder of the second
+        # on its own stream beside the decoder kernel of the first (the decoder leaves the VALU
+        # and the texture path idle, the encoder needs no LDS).  Measured at BASELINE config 4:
+        # the half forward pass then costs 0.01 instead of 0.05 ms, but two decoder launches cost
+        # 0.05 ms more than one (weights to LDS and gradient slabs twice) -- no net gain, so off.
+        self.split_fraction = 0.0
+        self._side2 = None
+        self._split_rows = 0
 
     def _tiny_mlp_plan(self):
         """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
@@ -152,9 +160,16 @@ class FusedStep:
         ws = self._workspace(n, train)
         x, feature_major = coords, False
         if self.encoder is not None:
+            h = 0
+            if train and self.use_tiny and self.split_fraction > 0 and n >= 4096:
+                # the second slice is encoded on its own stream beside the first slice's decoder
+                # kernel, which backward() queues
+                h = max(32, int(n * self.split_fraction) // 32 * 32)
+            self._split_rows = h  # rows [h, n) are encoded by backward(), see there
             with self._phase("hashgrid_fwd"):
-                x = ops.hashgrid_forward(self.encoder.desc, coords, self.encoder.table.data,
-                                         out=ws["enc"], feature_major=True)
+                x = ops.hashgrid_forward(self.encoder.desc, coords[:h] if h else coords,
+                                         self.encoder.table.data, out=ws["enc"],
+                                         feature_major=True)
             feature_major = True
         if self.use_tiny and not train:
             with self._phase("mlp_fwd"):
@@ -239,9 +254,26 @@ class FusedStep:
             # every gradient (tables, decoder) and the loss are OVERWRITTEN by the two kernels
             # below: no zeroing pass over the flat gradient buffer
             with self._phase("mlp_fused"):
-                ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"], self.tiny["grads"],
-                                   self.loss, d_x=ws["d_enc"], grad_divisor=float(self.world),
-                                   overwrite=True)
+                h, n = self._split_rows, coords.shape[0]
+                if h:
+                    if self._side2 is None:
+                        self._side2 = torch.cuda.Stream(device=coords.device)
+                    self._side2.wait_stream(torch.cuda.current_stream())  # starts with slice 1's decoder
+                    with torch.cuda.stream(self._side2):
+                        ops.hashgrid_forward(self.encoder.desc, coords[h:],
+                                             self.encoder.table.data, out=ws["enc"],
+                                             feature_major=True, row_offset=h)
+                    ops.tiny_mlp_train_slice(ws["enc"], target, 0, h, self.tiny["params"],
+                                             self.tiny["grads"], self.loss, ws["d_enc"],
+                                             grad_divisor=float(self.world), overwrite=True)
+                    torch.cuda.current_stream().wait_stream(self._side2)  # second slice encoded
+                    ops.tiny_mlp_train_slice(ws["enc"], target, h, n - h, self.tiny["params"],
+                                             self.tiny["grads"], self.loss, ws["d_enc"],
+                                             grad_divisor=float(self.world), overwrite=False)
+                else:
+                    ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"],
+                                       self.tiny["grads"], self.loss, d_x=ws["d_enc"],
+                                       grad_divisor=float(self.world), overwrite=True)
             with self._phase("hashgrid_bwd"):
                 self._pending = self._hash_backward(coords, ws["d_enc"], overwrite=True)
             return

@@ -625,6 +625,38 @@ def test_fused_step_paths_agree(amd):
     assert_close(results[0][1].cpu().numpy(), results[1][1].cpu().numpy(), REL_TOL, "params")
 
 
+def test_split_batch_step_equals_whole_batch_step(amd):
+    """The fused step cuts the batch in two slices (encoder of the second beside the decoder of
+    the first, mri_tiny_mlp_train_slice): same loss, gradients and updated parameters as the
+    one-slice step, for an even and a ragged split."""
+    import copy
+    torch.manual_seed(3)
+    net = amd.models.HashMLP(3, 16, 2, 19, 16, 512, dim_hidden=128, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False,
+                             final_activation=False, lr=5e-3).cuda()
+    with torch.no_grad():
+        net.encoder.table.uniform_(-0.5, 0.5)
+    x = torch.rand(50001, 3, device="cuda")
+    y = torch.rand(50001, 1, device="cuda")
+    results = []
+    for frac in (0.0, 0.5, 0.3):
+        m = copy.deepcopy(net)
+        step = amd.trainer.FusedStep(m, m.configure_optimizers())
+        step.split_fraction = frac
+        _, ws = step.forward(x, train=True)
+        assert (step._split_rows > 0) == (frac > 0)
+        step.backward(x, y, ws)
+        grad = step.flat.grad.clone()
+        loss = float(step.loss)
+        for _ in range(2):
+            step.train_step(x, y)
+        results.append((loss, grad, step.flat.param.clone()))
+    for loss, grad, param in results[1:]:
+        assert abs(loss - results[0][0]) <= REL_TOL * results[0][0]
+        assert_close(grad.cpu().numpy(), results[0][1].cpu().numpy(), REL_TOL, "gradients")
+        assert_close(param.cpu().numpy(), results[0][2].cpu().numpy(), 1e-4, "parameters")
+
+
 def test_bucketed_backward_equals_single_launch(amd):
     """Data-parallel mode computes the table gradient in level groups (so that each group's
     all-reduce can start early): same bits as the single launch."""
