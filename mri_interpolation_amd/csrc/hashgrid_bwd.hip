@@ -654,18 +654,34 @@ struct BinnedLaunch {
       int dense_blocks = 0, acc_blocks = 0;
       const BinPlan dense = select_levels(dense_all, level_mask, dense_blocks);
       const BinPlan sel = select_levels(plan, level_mask, acc_blocks);
-      bool any_split = false;
-      for (int e = 0; e < sel.n_entries; ++e) any_split |= sel.ws_offset[e] >= 0;
       if (dense.n_entries > 0 && phase != 1) {
         hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
                            dense, d_out, n, sl, sr, sf, w.max_bits);
         hipLaunchKernelGGL((dense_level_kernel<D, F>), dim3((unsigned)dense_blocks),
                            dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
                            w.max_bits, w.partial);
-        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, dense.n_entries), dim3(256), 0, st, tab,
-                           dense, F, n, d_table, w.max_bits, w.partial, overwrite);
       }
-      if (plan.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
+      // ONE finalize launch for everything that met in the int64 area: the dense levels and the
+      // binned levels whose bins were cut over entry ranges
+      BinPlan fin{};
+      for (int e = 0; e < dense.n_entries && phase != 1; ++e) {
+        fin.level_of[fin.n_entries] = dense.level_of[e];
+        fin.ws_offset[fin.n_entries++] = dense.ws_offset[e];
+      }
+      for (int e = 0; e < sel.n_entries && phase != 1; ++e)
+        if (sel.ws_offset[e] >= 0) {
+          fin.level_of[fin.n_entries] = sel.level_of[e];
+          fin.ws_offset[fin.n_entries++] = sel.ws_offset[e];
+        }
+      auto finalize = [&]() {
+        if (fin.n_entries > 0)
+          hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, fin.n_entries), dim3(256), 0, st, tab,
+                             fin, F, n, d_table, w.max_bits, w.partial, overwrite);
+      };
+      if (plan.n_entries == 0) {
+        finalize();
+        return check_launch("hashgrid backward (dense levels)");
+      }
       const int chunks = (int)ceil_div(n, plan.coords_per_block);
       const dim3 bin_grid((unsigned)chunks, plan.n_entries);
       if (phase != 2) {
@@ -678,7 +694,10 @@ struct BinnedLaunch {
                            w.counts, plan.total_bins);
       }
       if (phase == 1) return check_launch("hashgrid backward (count)");
-      if (sel.n_entries == 0) return check_launch("hashgrid backward (dense levels)");
+      if (sel.n_entries == 0) {
+        finalize();
+        return check_launch("hashgrid backward (dense levels)");
+      }
       hipLaunchKernelGGL((bin_kernel<D, F, true>), dim3((unsigned)chunks, sel.n_entries),
                          dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
                          w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
@@ -686,9 +705,7 @@ struct BinnedLaunch {
       hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
                          dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts, w.rec_slot,
                          w.rec_val, w.records, w.max_bits, d_table, w.partial, overwrite);
-      if (any_split)
-        hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, sel.n_entries), dim3(256), 0, st, tab,
-                           sel, F, n, d_table, w.max_bits, w.partial, overwrite);
+      finalize();
       return check_launch("hashgrid backward (binned)");
     } else {
       return fail(MRI_ERR_UNSUPPORTED, "binned backward supports dim <= 4, n_features <= 4");
