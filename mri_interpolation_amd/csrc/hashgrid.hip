@@ -9,16 +9,16 @@
 //   out = sum over corners (in corner order) of table[slot] * w  (separate multiply and add).
 //
 // Work decomposition (MI355X-first):
-//   forward / atomic backward: one thread per (coordinate, level), 256-thread blocks, and the
+//   forward / atomic backward: one thread (forward, F = 2: two lanes) per (coordinate, level),
+//     256-thread blocks, and the
 //     block -> level map keeps each level on ONE XCD (blockIdx % 8) so that a level's table
 //     (<= 4 MiB at T = 2^19, F = 2) is served from that XCD's 4 MiB L2 instead of every L2
 //     thrashing over all 40-60 MB of tables.
-//   LDS backward: "owner computes" -- a 1024-thread workgroup owns a slice of one level's
-//     table as 64-bit fixed-point accumulators in LDS (128 KiB), scans the batch, and adds
-//     only the corners that hash into its slice (ds_add_u64), then writes the slice back with
-//     coalesced stores.  Scattered global float atomics run ~17x below the coalesced atomic
-//     rate on gfx950 (MI355X_MICROARCH.md, Global float atomics): 3.6 ms for BASELINE
-//     config 4, against 0.2-0.3 ms for this kernel.
+//   the table gradient proper lives in hashgrid_bwd.hip (binning + fixed-point LDS accumulation);
+//     the global-atomic kernel here is its fallback for levels too large to bin, D > 4 or F > 4,
+//     and the cross-check of the tests (method 1).  Scattered global float atomics run ~17x below
+//     the coalesced atomic rate on gfx950 (MI355X_MICROARCH.md, Global float atomics): 3.6 ms for
+//     BASELINE config 4, against 0.23 ms for the binned path.
 #include "hashgrid_common.h"
 
 namespace mri {
