@@ -377,22 +377,28 @@ class Trainer:
         opt = self._prepare(model)
         model.train()
         done = False
+        # fused path over an on-device loader: ONE double-buffered pipeline for all epochs, the
+        # next batch (also the first one of the next epoch) is produced while a step runs
+        pipe = None
+        if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
+                and len(train_dataloaders) > 0:
+            train_dataloaders.set_epoch(0)
+            pipe = BatchPipeline(train_dataloaders)
         for epoch in range(self.max_epochs):
-            if hasattr(train_dataloaders, "set_epoch"):
+            if pipe is None and hasattr(train_dataloaders, "set_epoch"):
                 train_dataloaders.set_epoch(epoch)
             t0, seen = time.perf_counter(), 0
-            pipe = None
-            if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
-                    and len(train_dataloaders) > 0:
-                pipe = BatchPipeline(train_dataloaders)
+            if pipe is not None:
                 batches = ((b,) + pipe.current() for b in range(len(train_dataloaders)))
             else:
                 batches = ((b, x, y) for b, (x, y) in enumerate(train_dataloaders))
             for batch_idx, x, y in batches:
                 if pipe is not None:
-                    last = batch_idx == len(train_dataloaders) - 1
-                    loss = self.fused.train_step(x, y, None if last else pipe.produce_next)
-                    if not last:
+                    final = (epoch == self.max_epochs - 1
+                             and batch_idx == len(train_dataloaders) - 1) \
+                        or 0 < self.max_steps <= self.global_step + 1
+                    loss = self.fused.train_step(x, y, None if final else pipe.produce_next)
+                    if not final:
                         pipe.advance()
                 elif self.fused is not None:
                     loss = self.fused.train_step(x, y)
