@@ -142,6 +142,50 @@ def test_encoder_other_dims(amd, dim, feats):
                  REL_TOL, "bwd")
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_encoder_random_configurations(amd, seed):
+    """Seeded random encoders -- dimension, features, level count, table size (power of two or
+    not, through the resolution), isotropic or per-axis (V2) resolutions, batch size, coordinates
+    with out-of-range and grid-aligned rows -- forward and all three backward methods against
+    the oracle.  Sizes are chosen to put levels on every backward path: dense (few slices),
+    binned, split bins and global atomics."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.integers(1, 5))
+    feats = int(rng.choice([1, 2, 2, 4, 8]))
+    n_levels = int(rng.integers(1, 7))
+    log2t = int(rng.integers(6, 18))
+    n = int(rng.choice([1, 63, 64, 65, 700, 4097, 20000]))
+    if rng.random() < 0.5 or dim == 1:
+        base, finest = int(rng.integers(2, 12)), int(rng.integers(12, 200))
+        enc = amd.encoding.MultiResHashGrid(dim, n_levels, feats, log2t, base, finest).cuda()
+    else:
+        base = tuple(int(v) for v in rng.integers(2, 12, dim))
+        finest = tuple(int(b + v) for b, v in zip(base, rng.integers(1, 150, dim)))
+        enc = amd.encoding.MultiResHashGridV2(dim, n_levels, feats, log2t, base, finest).cuda()
+    res, sizes = ohash.resolutions_for(dim, n_levels, log2t, base, finest)
+    assert list(enc.sizes) == list(sizes)
+    with torch.no_grad():
+        enc.table.copy_(cuda(detrand.uniform(enc.table.numel(), seed + 1, -0.5, 0.5)
+                             .reshape(enc.table.shape)))
+    x = detrand.uniform(n * dim, seed + 2, -0.05, 1.05).reshape(n, dim).astype(np.float32)
+    x[: min(n, 4)] = [[0.0] * dim, [1.0] * dim, [0.5] * dim, [0.999999] * dim][: min(n, 4)]
+    xg = cuda(x)
+    tabs = [enc.table.data[a:b].cpu().clone().requires_grad_(True)
+            for a, b in (enc._row_span(i) for i in range(n_levels))]
+    want = ohash.encode(torch.from_numpy(x), tabs, res)
+    out = amd.ops.hashgrid_forward(enc.desc, xg, enc.table.data)
+    assert_close(out.cpu().numpy(), want.detach().numpy(), 1e-6, f"forward {dim=} {feats=}")
+    d = detrand.uniform(out.numel(), seed + 3, -1, 1).reshape(out.shape).astype(np.float32)
+    want.backward(torch.from_numpy(d))
+    want_grad = torch.cat([t.grad for t in tabs]).numpy()
+    for method in (0, 1, 2):
+        if method == 2 and (dim > 4 or feats > 4):
+            continue  # the binned path covers D <= 4, F <= 4 (method 0 falls back by itself)
+        got = torch.zeros_like(enc.table.data)
+        amd.ops.hashgrid_backward(enc.desc, xg, cuda(d), got, method=method)
+        assert_close(got.cpu().numpy(), want_grad, REL_TOL, f"backward method {method}")
+
+
 def test_cpu_tensors_are_rejected(amd):
     enc = amd.encoding.MultiResHashGrid(3, 4, 2, 12, 4, 32)  # parameters on the CPU
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -182,6 +226,42 @@ def test_linear_forward_backward(amd, m, n, k, act):
     dxt = ops.linear_backward_data(dy.cuda(), wg.detach(), dx_feature_major=True)
     dx = ops.linear_backward_data(dy.cuda(), wg.detach())
     assert_close(dxt.t().contiguous().cpu().numpy(), dx.cpu().numpy(), 1e-6, "feature-major dx")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_linear_random_shapes(amd, seed):
+    """Seeded random layer shapes (batch 1..3000, widths 1..300, every activation, with and
+    without bias): every tile shape, edge tiles, the staged and the direct epilogue and the
+    small-width kernels against torch on the CPU."""
+    rng = np.random.default_rng(2000 + seed)
+    ops = amd.ops
+    m = int(rng.choice([1, 31, 64, 129, 1000, 2049, 3000]))
+    n = int(rng.choice([1, 2, 4, 5, 32, 64, 65, 128, 200, 256, 300]))
+    k = int(rng.choice([1, 3, 8, 9, 32, 33, 64, 130, 256, 300]))
+    act = str(rng.choice(["identity", "relu", "sine", "gelu"]))
+    use_bias = bool(rng.random() < 0.7)
+    code = dict(identity=ops.ACT_IDENTITY, relu=ops.ACT_RELU, sine=ops.ACT_SINE,
+                gelu=ops.ACT_GELU)[act]
+    w0 = 30.0 if act == "sine" else 1.0
+    bound = 1.0 / np.sqrt(k) if act != "sine" else np.sqrt(6.0 / k) / 30.0
+    x = torch.from_numpy(detrand.uniform(m * k, seed + 1, -1, 1).reshape(m, k)).requires_grad_(True)
+    w = torch.from_numpy(detrand.uniform(n * k, seed + 2, -bound, bound).reshape(n, k)).requires_grad_(True)
+    b = torch.from_numpy(detrand.uniform(n, seed + 3, -bound, bound)).requires_grad_(True) if use_bias else None
+    z = torch.nn.functional.linear(x, w, b)
+    y = dict(identity=lambda t: t, relu=torch.relu, sine=lambda t: torch.sin(w0 * t),
+             gelu=torch.nn.functional.gelu)[act](z)
+    dy = torch.from_numpy(detrand.uniform(m * n, seed + 4, -1, 1).reshape(m, n))
+    y.backward(dy)
+    xg, wg = (t.detach().cuda().requires_grad_(True) for t in (x, w))
+    bg = b.detach().cuda().requires_grad_(True) if use_bias else None
+    yg = ops.linear_act(xg, wg, bg, code, w0)
+    yg.backward(dy.cuda())
+    tag = f"{m}x{k}->{n} {act} bias={use_bias}"
+    assert_close(yg.detach().cpu().numpy(), y.detach().numpy(), REL_TOL, "y " + tag)
+    assert_close(xg.grad.cpu().numpy(), x.grad.numpy(), REL_TOL, "dx " + tag)
+    assert_close(wg.grad.cpu().numpy(), w.grad.numpy(), REL_TOL, "dw " + tag)
+    if use_bias:
+        assert_close(bg.grad.cpu().numpy(), b.grad.numpy(), REL_TOL, "db " + tag)
 
 
 # ------------------------------------------------------------------------------ whole models
