@@ -646,21 +646,42 @@ def test_lds_backward_is_bitwise_reproducible(amd):
 
 
 @pytest.mark.parametrize("k_in,hidden,n", [(32, 128, 4096), (32, 128, 1000), (32, 64, 2500),
-                                           (8, 64, 777), (64, 64, 1024), (4, 128, 65)])
+                                           (8, 64, 777), (64, 64, 1024), (4, 128, 65),
+                                           (32, 128, 1), (32, 128, 33), (31, 128, 1001),
+                                           (32, 128, 70001), (17, 64, 129), (33, 64, 70003)])
 def test_tiny_mlp_fused_kernel(amd, k_in, hidden, n):
     """One-kernel forward + MSE + backward of the in->H->H->1 ReLU MLP against the oracle
     (torch autograd on the CPU), feature-major input and feature gradient."""
     ops = amd.ops
     assert ops.tiny_mlp_supported(k_in, hidden, 1)
     params = omlp.linear_init([k_in, hidden, hidden, 1], 7 + k_in)
-    x = torch.from_numpy(detrand.uniform(n * k_in, 1, -1, 1).reshape(n, k_in)).requires_grad_(True)
+    x = torch.from_numpy(detrand.uniform(n * k_in, 1, -1, 1).reshape(n, k_in))
     t = torch.from_numpy(detrand.uniform(n, 2, 0, 1).reshape(n, 1))
+    params32 = params
+    if n > 20000:
+        # sums of > 2e4 signed terms: the f32 oracle itself is ~1e-5 away from exact arithmetic
+        # (summation order), so the large batches are judged against the oracle in float64
+        params = [(w.double(), b.double()) for w, b in params]
+        x, t = x.double(), t.double()
+    x.requires_grad_(True)
     flat = [p for wb in params for p in wb]
     for p in flat:
         p.requires_grad_(True)
     y = omlp.relu_mlp_forward(x, params, final_activation=False)
     loss = omlp.mse_loss(y, t)
     loss.backward()
+    if n > 20000:
+        # float32 copies of the float64 results for the comparisons below
+        y = y.float()
+        x_grad = x.grad.float()
+        params = [(w.detach().float().requires_grad_(True), b.detach().float().requires_grad_(True))
+                  for w, b in params]
+        for (w, b), (w64, b64) in zip(params, [(flat[0], flat[1]), (flat[2], flat[3]), (flat[4], flat[5])]):
+            w.grad, b.grad = w64.grad.float(), b64.grad.float()
+        x = x.detach().float().requires_grad_(True)
+        x.grad = x_grad
+        t = t.float()
+        loss = loss.float()
 
     gp = [(w.detach().cuda(), b.detach().cuda()) for w, b in params]
     grads = [(torch.zeros_like(w), torch.zeros_like(b)) for w, b in gp]
