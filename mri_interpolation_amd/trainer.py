@@ -240,6 +240,23 @@ class FusedStep:
             pending.append(parallel.all_reduce_async(grad_slice))
         return pending
 
+    def _reduce_decoder_grads(self):
+        """Start the reduction of everything in the flat gradient buffer that is not the hash
+        table (the decoder's weights: complete as soon as its backward kernels are queued), so
+        that it runs beside the table-gradient kernels instead of behind the table's groups."""
+        if self.world <= 1 or self.grad_buckets <= 1 or self.encoder is None:
+            return []
+        f = self.encoder.n_features_per_level
+        t0 = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
+                                    if q is self.encoder.table)]
+        t1 = t0 + self.encoder.table.shape[0] * f
+        out = []
+        if t0 > 0:
+            out.append(parallel.all_reduce_async(self.flat.grad[:t0]))
+        if t1 < self.flat.numel:
+            out.append(parallel.all_reduce_async(self.flat.grad[t1:]))
+        return out
+
     def _deriv_of(self, i, ws):
         mode = ops.deriv_mode_for(self.layers[i].activation)
         if mode == ops.DERIV_MUL:
@@ -274,8 +291,9 @@ class FusedStep:
                     ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"],
                                        self.tiny["grads"], self.loss, d_x=ws["d_enc"],
                                        grad_divisor=float(self.world), overwrite=True)
+            first = self._reduce_decoder_grads()
             with self._phase("hashgrid_bwd"):
-                self._pending = self._hash_backward(coords, ws["d_enc"], overwrite=True)
+                self._pending = first + self._hash_backward(coords, ws["d_enc"], overwrite=True)
             return
         with self._phase("zero_grad"):
             self.flat.grad.zero_()
@@ -302,8 +320,9 @@ class FusedStep:
                     ops.linear_backward_data(dz, l.weight.data, ops.DERIV_NONE, None,
                                              dx=ws["d_enc"], dx_feature_major=True)
         if self.encoder is not None:
+            first = self._reduce_decoder_grads()
             with self._phase("hashgrid_bwd"):
-                self._pending = self._hash_backward(coords, ws["d_enc"])
+                self._pending = first + self._hash_backward(coords, ws["d_enc"])
 
     def train_step(self, coords, target, side_work=None) -> torch.Tensor:
         """One optimisation step; returns the (device) loss scalar of this rank's batch.
@@ -326,15 +345,7 @@ class FusedStep:
         self.backward(coords, target, ws)
         if self.world > 1:
             with self._phase("all_reduce"):
-                if self._pending:  # table levels are already in flight: add everything else
-                    f = self.encoder.n_features_per_level
-                    t0 = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
-                                                if q is self.encoder.table)]
-                    t1 = t0 + self.encoder.table.shape[0] * f
-                    if t0 > 0:
-                        self._pending.append(parallel.all_reduce_async(self.flat.grad[:t0]))
-                    if t1 < self.flat.numel:
-                        self._pending.append(parallel.all_reduce_async(self.flat.grad[t1:]))
+                if self._pending:  # decoder and table level groups are already in flight
                     parallel.wait_all(self._pending)
                 else:
                     parallel.all_reduce_sum(self.flat.grad)
