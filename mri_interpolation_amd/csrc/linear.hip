@@ -35,6 +35,9 @@ namespace mri {
 bool small_forward(const float* x, int64_t xrs, int64_t xcs, const float* w, const float* b,
                    int64_t m, int n, int k, int act, float w0, float* y, int64_t ldy, float* deriv,
                    int64_t ldd, hipStream_t st);
+bool small_backward_weight(const float* dy, int64_t lddy, const float* x, int64_t xrs, int64_t xcs,
+                           int64_t m, int n, int k, float* d_weight, float* d_bias,
+                           hipStream_t st);
 bool small_backward_data(const float* dy, int64_t lddy, const float* w, int64_t m, int n, int k,
                          int mode, const float* g, int64_t ldg, float* dx, int64_t lddx,
                          hipStream_t st);
@@ -611,6 +614,9 @@ extern "C" int mri_linear_backward_weight(const float* dy, int64_t lddy, const f
   MRI_REQUIRE(m >= 0 && n >= 1 && k >= 1, "bad shape m=%lld n=%d k=%d", (long long)m, n, k);
   if (m == 0) return MRI_OK;
   MRI_REQUIRE(dy && x && d_weight, "NULL device pointer");
+  if (small_backward_weight(dy, lddy, x, x_row_stride, x_col_stride, m, n, k, d_weight, d_bias,
+                            (hipStream_t)stream))
+    return check_launch("small_k_backward_weight_kernel");
   GemmArgs a{};
   a.p = make_operand(dy, 1, lddy);                     // P(i = n, c = m)
   a.q = make_operand(x, x_col_stride, x_row_stride);   // Q(j = k, c = m)

@@ -4,8 +4,9 @@
 // no reuse to speak of -- a 32x32 MFMA tile would be >= 90 % padding -- and are bound by streaming
 // the wide side once (M x 256 floats = 1 GiB at M = 2^20), so forward and backward-data run on the
 // VALU with 16-byte accesses and wave shuffles instead of going through linear.hip's tiles.
-// (Their weight gradients stay on the split-batch MFMA kernel, which measured 2-3x faster than a
-// VALU column sweep: 0.35 ms vs 0.97 ms for N = 1, K = 256, M = 2^20.)
+// (The weight gradient of a tiny OUTPUT stays on the split-batch MFMA kernel, which measured 2-3x
+// faster than a VALU column sweep: 0.35 ms vs 0.97 ms for N = 1, K = 256, M = 2^20; the weight
+// gradient of a tiny INPUT has its own streaming kernel below.)
 #include <math.h>
 
 #include <algorithm>
@@ -157,9 +158,70 @@ __global__ __launch_bounds__(256) void small_n_backward_data_kernel(
   }
 }
 
+// ---- K <= 8: dW[n][k] += sum_m dy[m][n] x[m][k], db[n] += sum_m dy[m][n] -------------------------
+// The first layer of a coordinate network: the contraction is the whole batch, the output N x 3.
+// A 128 x 32 MFMA tile would multiply 29 columns of zeros and streams dy at 2.4 TB/s; here a
+// thread owns one column n, a workgroup a range of rows whose (few) x values sit in LDS and are
+// read as broadcasts, and dy is read once with row-contiguous loads.
+constexpr int kWeightRows = 1024;  // rows per workgroup
+
+__global__ __launch_bounds__(256) void small_k_backward_weight_kernel(
+    const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t xrs,
+    int64_t xcs, int64_t m, int n, int k, float* __restrict__ d_weight,
+    float* __restrict__ d_bias) {
+  __shared__ float xs[kWeightRows * kSmallK];
+  const int64_t r0 = (int64_t)blockIdx.x * kWeightRows;
+  const int rows = (int)min((int64_t)kWeightRows, m - r0);
+  for (int e = threadIdx.x; e < rows * k; e += 256) {
+    const int r = e / k, kk = e - r * k;
+    xs[r * kSmallK + kk] = x[(r0 + r) * xrs + kk * xcs];
+  }
+  __syncthreads();
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= n) return;
+  float acc[kSmallK], sum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < kSmallK; ++kk) acc[kk] = 0.f;
+  const float* __restrict__ p = dy + r0 * lddy + col;
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {
+    float d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = p[(int64_t)(r + j) * lddy];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sum += d[j];
+#pragma unroll
+      for (int kk = 0; kk < kSmallK; ++kk)
+        if (kk < k) acc[kk] += d[j] * xs[(r + j) * kSmallK + kk];
+    }
+  }
+  for (; r < rows; ++r) {
+    const float d = p[(int64_t)r * lddy];
+    sum += d;
+#pragma unroll
+    for (int kk = 0; kk < kSmallK; ++kk)
+      if (kk < k) acc[kk] += d * xs[r * kSmallK + kk];
+  }
+#pragma unroll
+  for (int kk = 0; kk < kSmallK; ++kk)
+    if (kk < k) atomicAdd(d_weight + (int64_t)col * k + kk, acc[kk]);
+  if (d_bias) atomicAdd(d_bias + col, sum);
+}
+
 }  // namespace
 
 // ---- entry points used by linear.hip's extern "C" functions -------------------------------------
+bool small_backward_weight(const float* dy, int64_t lddy, const float* x, int64_t xrs, int64_t xcs,
+                           int64_t m, int n, int k, float* d_weight, float* d_bias,
+                           hipStream_t st) {
+  if (k > kSmallK || n < 64) return false;  // narrow outputs stay on the MFMA kernel
+  hipLaunchKernelGGL(small_k_backward_weight_kernel,
+                     dim3((unsigned)ceil_div(m, kWeightRows), (unsigned)ceil_div(n, 256)),
+                     dim3(256), 0, st, dy, lddy, x, xrs, xcs, m, n, k, d_weight, d_bias);
+  return true;
+}
+
 bool small_forward(const float* x, int64_t xrs, int64_t xcs, const float* w, const float* b,
                    int64_t m, int n, int k, int act, float w0, float* y, int64_t ldy, float* deriv,
                    int64_t ldd, hipStream_t st) {
