@@ -290,14 +290,12 @@ __global__ __launch_bounds__(256) void bin_prefix_kernel(uint32_t* __restrict__ 
 
 // ------------------------------------------------------------------------------ 5. accumulate
 template <int F>
-__global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
-    const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
-    const float* __restrict__ rec_val, int64_t records,
+__device__ __forceinline__ void bin_accumulate_body(
+    unsigned long long* __restrict__ acc, int b, const LevelTab& tab, const BinPlan& plan,
+    int64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+    const uint16_t* __restrict__ rec_slot, const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
     unsigned long long* __restrict__ partial, int overwrite) {
-  __shared__ unsigned long long acc[kAccWords];
-  const int b = blockIdx.x;
   int e = 0;
   while (e + 1 < plan.n_entries && b >= plan.acc_start[e + 1]) ++e;
   const int level = plan.level_of[e];
@@ -393,6 +391,18 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
   }
 }
 
+template <int F>
+__global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
+    const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
+    const float* __restrict__ rec_val, int64_t records,
+    const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
+    unsigned long long* __restrict__ partial, int overwrite) {
+  __shared__ unsigned long long acc[kAccWords];
+  bin_accumulate_body<F>(acc, blockIdx.x, tab, plan, n, offsets, counts, rec_slot, rec_val,
+                         records, max_bits, d_table, partial, overwrite);
+}
+
 // ------------------------------------------------------------------------- coarse levels
 // A level whose table is cut into only a few slices does not need records at all: a workgroup
 // (level, slice, coordinate range) can afford to evaluate the corners of every coordinate of its
@@ -425,12 +435,11 @@ __global__ __launch_bounds__(256) void dense_absmax_kernel(const BinPlan plan,
 }
 
 template <int D, int F>
-__global__ __launch_bounds__(kAccThreads) void dense_level_kernel(
-    const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
-    const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
-    const uint32_t* __restrict__ max_bits, unsigned long long* __restrict__ partial) {
-  __shared__ unsigned long long acc[kAccWords];
-  const int b = blockIdx.x;
+__device__ __forceinline__ void dense_level_body(
+    unsigned long long* __restrict__ acc, int b, const LevelTab& tab, const BinPlan& plan,
+    const float* __restrict__ x, const float* __restrict__ d_out, int64_t n, int64_t sl,
+    int64_t sr, int64_t sf, const uint32_t* __restrict__ max_bits,
+    unsigned long long* __restrict__ partial) {
   int e = 0;
   while (e + 1 < plan.n_entries && b >= plan.acc_start[e + 1]) ++e;
   const int level = plan.level_of[e];
@@ -472,6 +481,36 @@ __global__ __launch_bounds__(kAccThreads) void dense_level_kernel(
   unsigned long long* __restrict__ dst = partial + plan.ws_offset[e] + (uint64_t)base * F;
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
     if (acc[s]) atomicAdd(dst + s, acc[s]);
+}
+
+template <int D, int F>
+__global__ __launch_bounds__(kAccThreads) void dense_level_kernel(
+    const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
+    const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
+    const uint32_t* __restrict__ max_bits, unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long acc[kAccWords];
+  dense_level_body<D, F>(acc, blockIdx.x, tab, plan, x, d_out, n, sl, sr, sf, max_bits, partial);
+}
+
+// Dense levels and record accumulation in ONE launch: both bodies want a whole CU (1024 threads,
+// 128 KiB of LDS).  The accumulate workgroups of BASELINE config 4 (820 on 256 CUs) leave their
+// fourth round 80 % empty and the dense launch (192 workgroups) leaves a quarter of the CUs idle;
+// together they fill four rounds, the (longer) dense workgroups first.
+template <int D, int F>
+__global__ __launch_bounds__(kAccThreads) void dense_and_accumulate_kernel(
+    const LevelTab tab, const BinPlan dense, int dense_blocks, const BinPlan plan,
+    const float* __restrict__ x, const float* __restrict__ d_out, int64_t n, int64_t sl,
+    int64_t sr, int64_t sf, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
+    const float* __restrict__ rec_val, int64_t records, const uint32_t* __restrict__ max_bits,
+    float* __restrict__ d_table, unsigned long long* __restrict__ partial, int overwrite) {
+  __shared__ unsigned long long acc[kAccWords];
+  const int b = blockIdx.x;
+  if (b < dense_blocks)
+    dense_level_body<D, F>(acc, b, tab, dense, x, d_out, n, sl, sr, sf, max_bits, partial);
+  else
+    bin_accumulate_body<F>(acc, b - dense_blocks, tab, plan, n, offsets, counts, rec_slot,
+                           rec_val, records, max_bits, d_table, partial, overwrite);
 }
 
 // ------------------------------------------------------------------------------ 6. finalize
@@ -654,12 +693,15 @@ struct BinnedLaunch {
       int dense_blocks = 0, acc_blocks = 0;
       const BinPlan dense = select_levels(dense_all, level_mask, dense_blocks);
       const BinPlan sel = select_levels(plan, level_mask, acc_blocks);
+      // dense levels: their launch is merged with the record accumulation when the call has both
+      const bool fuse_dense = dense.n_entries > 0 && sel.n_entries > 0 && options().bwd_fuse_dense;
       if (dense.n_entries > 0 && phase != 1) {
         hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
                            dense, d_out, n, sl, sr, sf, w.max_bits);
-        hipLaunchKernelGGL((dense_level_kernel<D, F>), dim3((unsigned)dense_blocks),
-                           dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
-                           w.max_bits, w.partial);
+        if (!fuse_dense)
+          hipLaunchKernelGGL((dense_level_kernel<D, F>), dim3((unsigned)dense_blocks),
+                             dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
+                             w.max_bits, w.partial);
       }
       // ONE finalize launch for everything that met in the int64 area: the dense levels and the
       // binned levels whose bins were cut over entry ranges
@@ -702,9 +744,17 @@ struct BinnedLaunch {
                          dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
                          w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
                          w.records, w.max_bits);
-      hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
-                         dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts, w.rec_slot,
-                         w.rec_val, w.records, w.max_bits, d_table, w.partial, overwrite);
+      if (fuse_dense)
+        hipLaunchKernelGGL((dense_and_accumulate_kernel<D, F>),
+                           dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
+                           tab, dense, dense_blocks, sel, x, d_out, n, sl, sr, sf, w.offsets,
+                           w.counts, w.rec_slot, w.rec_val, w.records, w.max_bits, d_table,
+                           w.partial, overwrite);
+      else
+        hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
+                           dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts,
+                           w.rec_slot, w.rec_val, w.records, w.max_bits, d_table, w.partial,
+                           overwrite);
       finalize();
       return check_launch("hashgrid backward (binned)");
     } else {

@@ -177,6 +177,8 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
     options().xcd_affinity = value != 0;
   } else if (!strcmp(name, "bwd_lds_max_parts")) {
     options().bwd_lds_max_parts = value;
+  } else if (!strcmp(name, "bwd_fuse_dense")) {
+    options().bwd_fuse_dense = value != 0;
   } else if (!strcmp(name, "bwd_dense_blocks")) {
     options().bwd_dense_blocks = value < 1 ? 1 : value;
   } else if (!strcmp(name, "bwd_dense_max_parts")) {
