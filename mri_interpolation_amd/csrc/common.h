@@ -43,7 +43,7 @@ struct Options {
   int fwd_pair = 1;               // F = 2 forward: two lanes per (coordinate, level), see hashgrid.hip
   int mlp_stagger = 0;            // fused tiny MLP (H = 128): segments team 1 runs behind team 0 (0 = lockstep: measured best)
   int bwd_fuse_dense = 1;         // dense levels share the launch of the record accumulation (fills its last round)
-  int bwd_dense_blocks = 192;     // workgroups of the dense-level launch (all dense levels together)
+  int bwd_dense_blocks = 96;      // workgroups of the dense-level launch (all dense levels together)
   int bwd_dense_max_parts = 4;    // levels with at most this many table slices skip the records (measured optimum)
 };
 Options& options();

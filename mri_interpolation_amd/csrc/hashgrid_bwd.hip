@@ -591,9 +591,10 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, Bin
     records += n << D;
   }
   // Dense levels: every workgroup hashes ALL corners of its coordinate range and keeps those of
-  // its slice, so a workgroup's time is set by the length of that range alone.  One range length
-  // for all dense levels (the same number of splits), ~192 workgroups in all (measured optimum:
-  // more ranges mean more int64 merges): 37 -> 34 us at BASELINE config 4.
+  // its slice, so a workgroup's time is set by the length of that range alone: one range length
+  // for all dense levels (the same number of splits).  Their workgroups run in the launch of the
+  // record accumulation (dense_and_accumulate_kernel), ahead of its workgroups; ~96 of them
+  // measured best there (fewer: they become the long pole; more: more int64 merges).
   int dense_parts = 0;
   for (int e = 0; e < dense.n_entries; ++e) dense_parts += dense.parts[e];
   if (dense_parts > 0) {
