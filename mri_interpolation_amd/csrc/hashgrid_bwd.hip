@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
     uint32_t* __restrict__ chunk_hist, const uint32_t* __restrict__ chunk_base,
     const uint32_t* __restrict__ offsets, int chunks, uint16_t* __restrict__ rec_slot,
-    float* __restrict__ rec_val, int64_t records, uint32_t* __restrict__ max_bits) {
+    float* __restrict__ rec_val, int64_t records, uint32_t* __restrict__ max_bits,
+    uint32_t absmax_levels) {
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
@@ -135,6 +136,37 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   __shared__ uint32_t wg_max;
 
   const int e = blockIdx.y;
+  if (SCATTER && e >= plan.n_entries) {
+    // Extra rows of the scatter grid: max |d_out| of the dense levels (`absmax_levels`, one row
+    // per set bit), which the dense workgroups of the next launch need for their scale -- a
+    // launch of its own cost 6 us.
+    int level = -1;
+    for (int l = 0, k = e - plan.n_entries; l < MRI_MAX_LEVELS; ++l)
+      if ((absmax_levels >> l) & 1u) {
+        if (k-- == 0) {
+          level = l;
+          break;
+        }
+      }
+    if (level < 0) return;
+    if (threadIdx.x == 0) wg_max = 0u;
+    __syncthreads();
+    const float* __restrict__ gl = d_out + (int64_t)level * sl;
+    const int64_t i0 = (int64_t)blockIdx.x * plan.coords_per_block;
+    const int64_t i1 = min(n, i0 + plan.coords_per_block);
+    float gmax = 0.0f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += kBinThreads)
+#pragma unroll
+      for (int f = 0; f < F; ++f) gmax = fmaxf(gmax, fabsf(gl[i * sr + f * sf]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(max_bits + level, wg_max);
+    return;
+  }
   const int level = plan.level_of[e];
   const int parts = plan.parts[e];
   const uint32_t size = tab.size[level], magic = tab.magic[level];
@@ -696,7 +728,7 @@ struct BinnedLaunch {
       const BinPlan sel = select_levels(plan, level_mask, acc_blocks);
       // dense levels: their launch is merged with the record accumulation when the call has both
       const bool fuse_dense = dense.n_entries > 0 && sel.n_entries > 0 && options().bwd_fuse_dense;
-      if (dense.n_entries > 0 && phase != 1) {
+      if (dense.n_entries > 0 && phase != 1 && !fuse_dense) {
         hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
                            dense, d_out, n, sl, sr, sf, w.max_bits);
         if (!fuse_dense)
@@ -730,7 +762,7 @@ struct BinnedLaunch {
       if (phase != 2) {
         hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
                            x, d_out, n, sl, sr, sf, w.chunk_hist, w.chunk_base, w.offsets, chunks,
-                           w.rec_slot, w.rec_val, w.records, w.max_bits);
+                           w.rec_slot, w.rec_val, w.records, w.max_bits, 0u);
         hipLaunchKernelGGL(bin_chunk_scan_kernel, dim3((unsigned)plan.total_bins), dim3(64), 0, st,
                            w.chunk_hist, w.chunk_base, w.cursor, chunks);
         hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(256), 0, st, w.cursor, w.offsets,
@@ -741,10 +773,14 @@ struct BinnedLaunch {
         finalize();
         return check_launch("hashgrid backward (dense levels)");
       }
-      hipLaunchKernelGGL((bin_kernel<D, F, true>), dim3((unsigned)chunks, sel.n_entries),
+      uint32_t absmax_levels = 0;  // with the fused launch: dense absmax rides on the scatter grid
+      if (fuse_dense)
+        for (int e = 0; e < dense.n_entries; ++e) absmax_levels |= 1u << dense.level_of[e];
+      hipLaunchKernelGGL((bin_kernel<D, F, true>),
+                         dim3((unsigned)chunks, sel.n_entries + (fuse_dense ? dense.n_entries : 0)),
                          dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
                          w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
-                         w.records, w.max_bits);
+                         w.records, w.max_bits, absmax_levels);
       if (fuse_dense)
         hipLaunchKernelGGL((dense_and_accumulate_kernel<D, F>),
                            dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
