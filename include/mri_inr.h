@@ -69,7 +69,7 @@ const char* mri_version(void);
 const char* mri_last_error(void);
 /* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level" n,
  * "bwd_dense_max_parts" n, "bwd_dense_blocks" n, "bwd_fuse_dense" 0/1, "fwd_pair" 0/1,
- * "mlp_stagger" 0..16); results stay within fp32 summation-order noise. */
+ * "mlp_stagger" 0..8); results stay within fp32 summation-order noise. */
 int mri_set_option(const char* name, int32_t value);
 
 /* ---- hash-grid encoding --------------------------------------------------------------
