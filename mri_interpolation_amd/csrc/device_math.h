@@ -31,6 +31,47 @@ __device__ __forceinline__ void sincos_fast(float u, float* s_out, float* c_out)
   *c_out = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// Two arguments at once on the packed f32 FMA / multiply (v_pk_fma_f32, v_pk_mul_f32: two elements
+// of f32 per instruction slot): the reduction and both polynomials are FMA chains, only the
+// rounding, the quadrant logic and the range check stay per element.  Same arithmetic as
+// sincos_fast, operation for operation.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sincos_fast2(float u0, float u1, float* s0, float* c0, float* s1,
+                                             float* c1) {
+  if (fabsf(u0) > 8192.0f || fabsf(u1) > 8192.0f) {
+    sincos_fast(u0, s0, c0);
+    sincos_fast(u1, s1, c1);
+    return;
+  }
+  const f32x2 u = {u0, u1};
+  const f32x2 t = u * 0.636619772367581343f;
+  const f32x2 k = {rintf(t.x), rintf(t.y)};
+  f32x2 r = __builtin_elementwise_fma(k, (f32x2)(-1.57079625129699707031e+00f), u);
+  r = __builtin_elementwise_fma(k, (f32x2)(-7.54978941586159635335e-08f), r);
+  r = __builtin_elementwise_fma(k, (f32x2)(-5.39030252995776476554e-15f), r);
+  const f32x2 z = r * r;
+  f32x2 ps = __builtin_elementwise_fma((f32x2)(-1.9515295891e-4f), z, (f32x2)(8.3321608736e-3f));
+  ps = __builtin_elementwise_fma(ps, z, (f32x2)(-1.6666654611e-1f));
+  const f32x2 sn = __builtin_elementwise_fma(ps * z, r, r);
+  f32x2 pc = __builtin_elementwise_fma((f32x2)(2.443315711809948e-5f), z,
+                                       (f32x2)(-1.388731625493765e-3f));
+  pc = __builtin_elementwise_fma(pc, z, (f32x2)(4.166664568298827e-2f));
+  const f32x2 half = __builtin_elementwise_fma((f32x2)(-0.5f), z, (f32x2)(1.0f));
+  const f32x2 cs = __builtin_elementwise_fma(pc * z, z, half);
+  {
+    const int q = (int)k.x & 3;
+    const float a = (q & 1) ? cs.x : sn.x, b = (q & 1) ? sn.x : cs.x;
+    *s0 = (q & 2) ? -a : a;
+    *c0 = ((q + 1) & 2) ? -b : b;
+  }
+  {
+    const int q = (int)k.y & 3;
+    const float a = (q & 1) ? cs.y : sn.y, b = (q & 1) ? sn.y : cs.y;
+    *s1 = (q & 2) ? -a : a;
+    *c1 = ((q + 1) & 2) ? -b : b;
+  }
+}
+
 __device__ __forceinline__ float gelu_f(float z) {
   return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
 }

@@ -432,6 +432,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
           const float bj = a.bias ? a.bias[j0 + (wj * TJ + tj) * 32 + l31] : 0.f;
+          if (a.act == MRI_ACT_SINE) {  // two elements per packed-f32 instruction slot
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              float s0, c0, s1, c1;
+              sincos_fast2(a.w0 * (acc[ti][tj][r] + bj), a.w0 * (acc[ti][tj][r + 1] + bj), &s0,
+                           &c0, &s1, &c1);
+              acc[ti][tj][r] = s0, acc[ti][tj][r + 1] = s1;
+              dv[ti][tj][r] = a.w0 * c0, dv[ti][tj][r + 1] = a.w0 * c1;
+            }
+            continue;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[ti][tj][r] + bj, d = 1.0f;
