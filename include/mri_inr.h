@@ -235,7 +235,10 @@ int mri_mse_loss(const float* pred, const float* target, int64_t count, float gr
 /* ---- optimiser -------------------------------------------------------------------------
  * torch.optim.Adam, single step over one flat buffer (reference models.py:68-70; defaults
  * betas (0.9, 0.999), eps 1e-8, no weight decay).  `step` is the 1-based step count.
- * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum).
+ * The four pointers may be any 4-byte aligned range of their buffers as long as they share
+ * one offset within a 16-byte line (the same slice of four 16-byte aligned buffers does):
+ * data-parallel ranks step each level group as soon as its reduction has landed. */
 int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t count, double lr, double beta1, double beta2, double eps,
                   int32_t step, float grad_scale, void* stream);

@@ -58,7 +58,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    int64_t count, float one_minus_b1, float b2,
                                                    float one_minus_b2, float neg_step_size,
-                                                   float bc2_sqrt, float eps, float grad_scale) {
+                                                   float bc2_sqrt, float eps, float grad_scale,
+                                                   int head) {
+  // p/g/m/v point at the first 16-byte aligned element of the range; the `head` (< 4) elements in
+  // front of it (a range that starts inside a float4, e.g. a level group of the hash table) are
+  // taken one each by the first threads of block 0
+  if (blockIdx.x == 0 && (int)threadIdx.x < head) {
+    const int64_t e = (int64_t)threadIdx.x - head;
+    const float gr = g[e] * grad_scale;
+    m[e] = m[e] + (gr - m[e]) * one_minus_b1;
+    v[e] = v[e] * b2 + (one_minus_b2 * gr) * gr;
+    const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
+    p[e] = p[e] + (neg_step_size * m[e]) / denom;
+  }
   const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (base >= count) return;
   if (base + 3 < count) {
@@ -215,19 +227,24 @@ extern "C" int mri_adam_step(float* param, const float* grad, float* exp_avg, fl
   MRI_REQUIRE(count >= 0 && step >= 1, "bad count/step");
   if (count == 0) return MRI_OK;
   MRI_REQUIRE(param && grad && exp_avg && exp_avg_sq, "NULL device pointer");
-  MRI_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
-                reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) &
-               15) == 0,
-              "Adam buffers must be 16-byte aligned");
+  // any 4-byte aligned range of the flat buffers, as long as the four pointers sit at the same
+  // offset inside a 16-byte line (they do when they are the same slice of four aligned buffers)
+  const uintptr_t mis = reinterpret_cast<uintptr_t>(param) & 15;
+  MRI_REQUIRE((mis & 3) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == mis &&
+                  (reinterpret_cast<uintptr_t>(exp_avg) & 15) == mis &&
+                  (reinterpret_cast<uintptr_t>(exp_avg_sq) & 15) == mis,
+              "Adam buffers must share one 4-byte aligned offset within a 16-byte line");
+  const int head = (int)std::min<int64_t>(count, mis ? (int64_t)(16 - mis) / 4 : 0);
+  param += head, grad += head, exp_avg += head, exp_avg_sq += head, count -= head;
   // scalar prefactors in double, as torch computes them on the host
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   const float neg_step_size = (float)(-(lr / bc1));
   const float bc2_sqrt = (float)sqrt(bc2);
-  const int64_t blocks = ceil_div(ceil_div(count, 4), 256);
+  const int64_t blocks = std::max<int64_t>(1, ceil_div(ceil_div(count, 4), 256));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      param, grad, exp_avg, exp_avg_sq, count, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), neg_step_size, bc2_sqrt, (float)eps, grad_scale);
+                     (float)(1.0 - beta2), neg_step_size, bc2_sqrt, (float)eps, grad_scale, head);
   return check_launch("adam_kernel");
 }
 

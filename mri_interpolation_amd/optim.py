@@ -77,7 +77,9 @@ class Adam:
                 p.grad = None
 
     @torch.no_grad()
-    def step(self):
+    def begin_step(self):
+        """Open step number step_count + 1; every element is then updated exactly once, by
+        step() in one launch or by step_range() piecewise (elementwise rule: same result)."""
         flat = self.flatten()
         for p, off in zip(flat.params, flat.offsets):
             # autograd may have replaced the view (first backward before flatten()):
@@ -86,9 +88,19 @@ class Adam:
                 flat.grad[off:off + p.numel()].copy_(g.reshape(-1))
                 p.grad = flat.grad[off:off + p.numel()].view(p.shape)
         self.step_count += 1
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int):
+        """Update flat elements [lo, hi) for the step opened by begin_step()."""
+        flat = self.flatten()
         lr = self.param_groups[0]["lr"]
-        ops.adam_step(flat.param, flat.grad, flat.exp_avg, flat.exp_avg_sq, lr, self.betas[0],
-                      self.betas[1], self.eps, self.step_count, self.grad_scale)
+        ops.adam_step(flat.param[lo:hi], flat.grad[lo:hi], flat.exp_avg[lo:hi],
+                      flat.exp_avg_sq[lo:hi], lr, self.betas[0], self.betas[1], self.eps,
+                      self.step_count, self.grad_scale)
+
+    def step(self):
+        self.begin_step()
+        self.step_range(0, self.flatten().numel)
 
     def state_dict(self):
         f = self.flatten()

@@ -237,8 +237,13 @@ class FusedStep:
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
                                   method=self.bwd_method, prepared=counted, overwrite=overwrite,
                                   level_mask=mask)
-            pending.append(parallel.all_reduce_async(grad_slice))
+            pending.append(self._reduce_async(grad_slice))
         return pending
+
+    def _reduce_async(self, grad_slice):
+        """(handle, lo, hi): a started reduction of flat.grad[lo:hi]."""
+        lo = grad_slice.storage_offset() - self.flat.grad.storage_offset()
+        return parallel.all_reduce_async(grad_slice), lo, lo + grad_slice.numel()
 
     def _reduce_decoder_grads(self):
         """Start the reduction of everything in the flat gradient buffer that is not the hash
@@ -252,9 +257,9 @@ class FusedStep:
         t1 = t0 + self.encoder.table.shape[0] * f
         out = []
         if t0 > 0:
-            out.append(parallel.all_reduce_async(self.flat.grad[:t0]))
+            out.append(self._reduce_async(self.flat.grad[:t0]))
         if t1 < self.flat.numel:
-            out.append(parallel.all_reduce_async(self.flat.grad[t1:]))
+            out.append(self._reduce_async(self.flat.grad[t1:]))
         return out
 
     def _deriv_of(self, i, ws):
@@ -343,14 +348,23 @@ class FusedStep:
         _, ws = self.forward(coords, train=True)
         self._pending = []
         self.backward(coords, target, ws)
-        if self.world > 1:
+        if self.world > 1 and self._pending:
+            # decoder and table level groups are already in flight, in this order; each one is
+            # stepped as soon as its sum has landed, beside the reductions still running (Adam is
+            # elementwise: the pieces give bit for bit what one launch over the buffer gives)
+            if sum(hi - lo for _, lo, hi in self._pending) != self.flat.numel:
+                raise RuntimeError("gradient groups do not cover the flat buffer exactly once")
             with self._phase("all_reduce"):
-                if self._pending:  # decoder and table level groups are already in flight
-                    parallel.wait_all(self._pending)
-                else:
+                self.opt.begin_step()
+                for handle, lo, hi in self._pending:
+                    parallel.wait_all([handle])
+                    self.opt.step_range(lo, hi)
+        else:
+            if self.world > 1:
+                with self._phase("all_reduce"):
                     parallel.all_reduce_sum(self.flat.grad)
-        with self._phase("adam"):
-            self.opt.step()
+            with self._phase("adam"):
+                self.opt.step()
         if side_work is not None:
             side_work()
         return self.loss

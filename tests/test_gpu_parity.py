@@ -801,6 +801,47 @@ def test_bucketed_backward_equals_single_launch(amd):
         for st in steps:
             st.train_step(x, y)
     assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+    # several ranks: every group is stepped right behind its own reduction (mri_adam_step on
+    # ranges that start inside a float4: 29791 rows x 2 floats) -> bit for bit the parameters
+    # of one reduction + one Adam launch over the whole buffer
+    nets = [copy.deepcopy(net) for _ in range(2)]
+    steps = [amd.trainer.FusedStep(m, m.configure_optimizers()) for m in nets]
+    for st, buckets in zip(steps, (1, 4)):
+        st.world, st.grad_buckets = 2, buckets
+    for _ in range(3):
+        for st in steps:
+            st.train_step(x, y)
+    assert len(steps[1]._pending) == 5 and steps[1].opt.step_count == 3
+    assert any(lo % 4 for _, lo, _ in steps[1]._pending)
+    assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+    assert torch.equal(steps[0].opt.flat.exp_avg_sq, steps[1].opt.flat.exp_avg_sq)
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3])
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5, 1027, 70001])
+def test_adam_step_ranges(amd, offset, count):
+    """mri_adam_step on a range that starts anywhere inside a float4: the range gets the oracle's
+    Adam (three steps), its neighbours in the flat buffers are not touched."""
+    g = torch.Generator().manual_seed(100 * count + offset)
+    total = offset + count + 7
+    p0 = torch.randn(total, generator=g)
+    grads = [torch.randn(total, generator=g) * 0.1 for _ in range(3)]
+    want_p = p0[offset:offset + count].clone()
+    ref = omlp.Adam([want_p], lr=5e-3)
+    bufs = [t.cuda() for t in (p0, torch.zeros(total), torch.zeros(total))]
+    for t, gr in enumerate(grads, start=1):
+        ref.step([gr[offset:offset + count]])
+        gd = gr.cuda()
+        amd.ops.adam_step(bufs[0][offset:offset + count], gd[offset:offset + count],
+                          bufs[1][offset:offset + count], bufs[2][offset:offset + count],
+                          5e-3, 0.9, 0.999, 1e-8, t)
+    got = bufs[0].cpu()
+    assert_close(got[offset:offset + count], want_p, 1e-6, "param")
+    assert_close(bufs[2].cpu()[offset:offset + count], ref.v[0], 1e-6, "exp_avg_sq")
+    outside = torch.ones(total, dtype=torch.bool)
+    outside[offset:offset + count] = False
+    assert torch.equal(got[outside], p0[outside])
+    assert not bufs[1].cpu()[outside].any() and not bufs[2].cpu()[outside].any()
 
 
 def test_backward_level_mask(amd):
