@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "libmri_prof.so")
+LIB = os.environ.get("MRI_PROF_LIB") or os.path.join(ROOT, "tools", "libmri_prof.so")
 
 
 def build():
