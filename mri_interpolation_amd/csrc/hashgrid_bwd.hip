@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
       uint32_t h0[D];
 #pragma unroll
-      for (int d = 0; d < D; ++d) h0[d] = (uint32_t)(int)(x[i * D + d] * res[d]) * kPrimes[d];
+      for (int d = 0; d < D; ++d) h0[d] = cell_low32(x[i * D + d] * res[d]) * kPrimes[d];
 #pragma unroll
       for (int nb = 0; nb < (1 << D); ++nb) {
         uint32_t h = 0;

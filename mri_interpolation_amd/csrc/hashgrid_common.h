@@ -33,15 +33,25 @@ struct Cell {
   float f[D];      // fractional position
 };
 
+// Cell index of a scaled coordinate: truncation toward zero as torch .long() (int64), of which
+// the hash keeps the low 32 bits (reference encoding.py:73: `(ind * prime) & 0xFFFFFFFF`).  Below
+// 2^31 that is the hardware float -> int32 conversion; a per-axis resolution may grow far beyond
+// that (V2's growth exponent), where the saturating conversion would differ: such
+// positions are integer-valued floats, converted through int64 on a path no usual level takes.
+__device__ __forceinline__ uint32_t cell_low32(float pos) {
+  if (__builtin_expect(fabsf(pos) < 2147483648.0f, 1)) return (uint32_t)(int)pos;
+  return (uint32_t)(unsigned long long)(long long)pos;
+}
+
 template <int D>
 __device__ __forceinline__ Cell<D> locate(const float* __restrict__ x, int64_t i, const float* res) {
   Cell<D> c;
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    float pos = x[i * D + d] * res[d];
-    int cell = (int)pos;  // truncation toward zero, as torch .long()
-    c.f[d] = pos - (float)cell;
-    c.h0[d] = (uint32_t)cell * kPrimes[d];
+    const float pos = x[i * D + d] * res[d];
+    // pos - float(cell): for |pos| >= 2^24 the position is its own cell (fraction 0)
+    c.f[d] = fabsf(pos) < 16777216.0f ? pos - (float)(int)pos : 0.0f;
+    c.h0[d] = cell_low32(pos) * kPrimes[d];
   }
   return c;
 }

@@ -142,7 +142,7 @@ def test_encoder_other_dims(amd, dim, feats):
                  REL_TOL, "bwd")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [320])  # 320: a resolution of 2.8e9 (> int32)
 def test_encoder_random_configurations(amd, seed):
     """Seeded random encoders -- dimension, features, level count, table size (power of two or
     not, through the resolution), isotropic or per-axis (V2) resolutions, batch size, coordinates
