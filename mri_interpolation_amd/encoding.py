@@ -108,6 +108,8 @@ class _HashGridBase(nn.Module):
         self.table = nn.Parameter(table)
         self.desc = ops.make_grid_desc(dim, self.resolutions, self.sizes, n_features_per_level)
         self.levels = [_LevelView(self, i) for i in range(n_levels)]
+        # isotropic levels only: V2 holds its resolutions as float32 tensors, which never raise
+        self._too_fine = isotropic and any(r[0] >= 2 ** 63 for r in self.resolutions)
         self.input_dim = dim
         self.output_dim = n_levels * n_features_per_level
 
@@ -115,6 +117,10 @@ class _HashGridBase(nn.Module):
         return self._starts[i], self._starts[i + 1]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._too_fine:
+            # the reference multiplies by the level's Python-int resolution (encoding.py:110);
+            # torch refuses an int beyond int64 with exactly this error, at the first forward
+            raise OverflowError("int too big to convert")
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         if torch.is_grad_enabled() and self.table.requires_grad:

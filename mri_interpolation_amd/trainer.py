@@ -70,6 +70,8 @@ class FusedStep:
         if plan is None:
             raise ValueError("model is not a fusable chain")
         self.encoder, self.layers = plan
+        if self.encoder is not None and getattr(self.encoder, "_too_fine", False):
+            raise OverflowError("int too big to convert")  # what encoder.forward raises
         self.opt = optimizer
         self.flat = optimizer.flatten()
         self.world = world
