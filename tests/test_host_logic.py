@@ -166,3 +166,16 @@ def test_phantom_4d_is_a_moving_3d_phantom():
     v3 = phantom_volume((12, 10, 6), device="cpu")
     assert v3.shape == (12, 10, 6) and float(v3.min()) == 0.0 and float(v3.max()) == 1.0
 
+
+
+def test_resolution_beyond_int64_raises_like_the_reference():
+    """base_resolution 2 makes the growth factor finest / base per level: level 11
+    of this grid has a resolution of 1.9e23.  The reference multiplies the coordinates by that
+    Python int and torch raises OverflowError at the first forward; so does the drop-in (before
+    anything touches the GPU).  Per-axis (V2) grids hold float32 resolutions and never raise."""
+    enc = encoding.MultiResHashGrid(2, 12, 2, 8, 2, 245)
+    assert enc.resolutions[-1][0] > 2 ** 63 and list(enc.sizes)[-1] == 256
+    with pytest.raises(OverflowError, match="int too big to convert"):
+        enc(torch.rand(4, 2))
+    assert not encoding.MultiResHashGrid(2, 4, 2, 8, 2, 245)._too_fine
+    assert not encoding.MultiResHashGridV2(2, 12, 2, 8, (2, 2), (245, 245))._too_fine
