@@ -63,6 +63,40 @@ def test_argument_validation_without_gpu(lib):
     assert need >= (1 << 10) * 8 * 12
 
 
+def test_every_entry_point_rejects_null_buffers_before_touching_the_device(lib):
+    """A non-empty call with NULL buffers (or an impossible range) returns -1 with a message
+    from every compute entry point; nothing is launched, so this runs without a GPU."""
+    from mri_interpolation_amd import ops
+    h = lib.load()
+    desc = C.byref(ops.make_grid_desc(3, [[16, 16, 16]], [4096], 2))
+    calls = {
+        "mri_hashgrid_forward": (desc, None, 8, None, None, 2, 2, 1, None),
+        "mri_hashgrid_backward": (desc, None, None, 8, 2, 2, 1, None, 0, None, 0, None),
+        "mri_hashgrid_backward_levels": (desc, None, None, 8, 2, 2, 1, None, 0, 1, None, 0, None),
+        "mri_hashgrid_backward_prepare": (desc, None, 8, 0, None, 0, None),
+        "mri_linear_forward": (None, 4, 1, None, None, 8, 4, 4, 0, 1.0, None, 4, None, 0, None),
+        "mri_linear_backward_data": (None, 4, None, 4, 4, 4, 0, None, 4, None, 4, 4, None),
+        "mri_linear_backward_weight": (None, 4, None, 4, 4, 4, 4, 4, None, None, None),
+        "mri_apply_deriv": (None, 4, 1, None, 4, 4, 4, None),
+        "mri_frequency_forward": (None, 3, 8, 3, 4, None, 24, None),
+        "mri_frequency_backward": (None, 3, None, 24, 8, 3, 4, None, 3, None),
+        "mri_mse_loss": (None, None, 8, 1.0, None, None, None),
+        "mri_tiny_mlp_forward": (None, 8, 32, 128, None, None, None, None, None, None, None, None),
+        "mri_tiny_mlp_train": (None, None, 8, 32, 128) + (None,) * 6 + (1.0,) + (None,) * 10
+                              + (0, None),
+        "mri_adam_step": (None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None),
+        "mri_sample_indices": (1, 0, 10, 5, 4, None, None),
+        "mri_gather_batch": (None, 4, 3, None, None, None, None, None, None, None),
+    }
+    for name, args in calls.items():
+        assert len(args) == len(lib.SIGNATURES[name]), name
+        assert getattr(h, name)(*args) == -1, name
+        assert h.mri_last_error().decode(), name
+    assert h.mri_hashgrid_forward(desc, None, -1, None, None, 2, 2, 1, None) == -1
+    assert "out of range" in h.mri_last_error().decode()
+    assert h.mri_tiny_mlp_supported(32, 128, 1) == 1 and h.mri_tiny_mlp_supported(64, 128, 1) == 0
+
+
 def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(lib, "_lib", None)
     monkeypatch.setattr(lib, "_LIB_PATH", "/nonexistent/libmri_inr.so")
