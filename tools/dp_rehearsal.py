@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Data-parallel rehearsal of the fused HIP step with real process-group reductions.
+
+    MRI_DIST_BACKEND=gloo MRI_SINGLE_DEVICE=1 python -m torch.distributed.run --nnodes=1 \\
+        --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_rehearsal.py
+
+(on an 8-GPU node: drop the two variables, RCCL is used).  Every rank trains the same model on
+its own batches for a few steps -- level-group reductions started asynchronously, each group
+Adam-stepped behind its own reduction -- then
+  * all replicas must hold bitwise identical parameters, and
+  * rank 0 repeats the run in ONE process on the concatenated batches (mean of equal-sized means
+    = global mean): parameters within 1e-5 of the data-parallel ones.
+Not a pytest case: a GPU test process must not start other programs (see tests/conftest.py).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+from mri_interpolation_amd import models, parallel, trainer
+
+
+def build(kind):
+    torch.manual_seed(1337)
+    if kind == "hash":
+        net = models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
+                             lr=5e-3)
+        with torch.no_grad():
+            net.encoder.table.uniform_(-0.5, 0.5)
+        return net
+    return models.SirenNet(dim_in=3, dim_hidden=64, dim_out=1, n_layers=3, lr=1e-4)
+
+
+def batches(rank, steps, n, lo):
+    g = torch.Generator().manual_seed(100 + rank)
+    return [(torch.rand(n, 3, generator=g) * (1 - lo) + lo, torch.rand(n, 1, generator=g))
+            for _ in range(steps)]
+
+
+def main():
+    rank, world, local = parallel.init()
+    assert world > 1, "launch with torchrun, 2 or more ranks"
+    torch.cuda.set_device(local)
+    steps, n = 4, 20001
+    for kind, lo in (("hash", 0.0), ("siren", -1.0)):
+        net = build(kind).cuda()
+        step = trainer.FusedStep(net, net.configure_optimizers(), world)
+        mine = batches(rank, steps, n, lo)
+        for x, y in mine:
+            step.train_step(x.cuda(), y.cuda())
+        torch.cuda.synchronize()
+        flat = step.flat.param.detach().cpu()
+        mine_flat = flat if dist.get_backend() == "gloo" else flat.cuda()  # RCCL gathers on the device
+        gathered = [torch.empty_like(mine_flat) for _ in range(world)]
+        dist.all_gather(gathered, mine_flat)
+        assert all(torch.equal(gathered[0], t) for t in gathered), f"{kind}: replicas differ"
+        if rank == 0:
+            ref = build(kind).cuda()
+            single = trainer.FusedStep(ref, ref.configure_optimizers(), 1)
+            everyone = [batches(r, steps, n, lo) for r in range(world)]
+            for k in range(steps):
+                x = torch.cat([everyone[r][k][0] for r in range(world)])
+                y = torch.cat([everyone[r][k][1] for r in range(world)])
+                single.train_step(x.cuda(), y.cuda())
+            want = single.flat.param.detach().cpu()
+            err = float((flat - want).abs().max() / want.abs().max())
+            print(f"{kind}: {world} replicas bitwise identical after {steps} steps "
+                  f"({len(step._pending)} gradient groups per step); vs one process on the "
+                  f"concatenated batches: max |diff| / max |param| = {err:.2e}", flush=True)
+            assert err <= 1e-5, f"{kind}: data-parallel result differs from the single process"
+        parallel.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("dp rehearsal ok")
+
+
+if __name__ == "__main__":
+    main()
