@@ -125,8 +125,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
-    ap.add_argument("--psnr-steps", type=int, default=500,
-                    help="total training steps before the PSNR evaluation (0 = skip)")
+    ap.add_argument("--psnr-steps", type=int, default=None,
+                    help="total training steps before the PSNR evaluation (0 = skip; default 2000, "
+                         "SIREN workloads 200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
@@ -156,6 +157,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     w = WORKLOADS[args.workload]
+    if args.psnr_steps is None:  # 2,000 steps (1.3 s of hash steps; SIREN: 200 = 4 s)
+        args.psnr_steps = 2000 if w["model"] == "hash" else 200
 
     # synthetic volume in HBM, this rank's z-slab, on-device batch generation
     vol = datamodules.phantom_volume(w["shape"], device=dev)
