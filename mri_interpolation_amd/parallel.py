@@ -26,6 +26,10 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the process group described by the environment; no-op for a single process."""
     rank, world, local = env_world()
+    # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC
+    # mode is not supported by every host driver (hipIpcGetMemHandle: invalid argument).  Only a
+    # default: an explicit setting of the launcher wins, and it is read when HIP initialises.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:  # "nccl" is RCCL on ROCm; MRI_DIST_BACKEND=gloo rehearses on one GPU
             backend = os.environ.get("MRI_DIST_BACKEND",
