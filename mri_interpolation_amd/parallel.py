@@ -112,4 +112,7 @@ def all_reduce_max(value: float, device) -> float:
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":  # name the device: no guessing, no warning
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
