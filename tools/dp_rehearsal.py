@@ -11,7 +11,8 @@ Adam-stepped behind its own reduction -- then
   * rank 0 repeats the run in ONE process on the concatenated batches (mean of equal-sized means
     = global mean): same first gradient to rounding (1e-6), same parameters to 1e-5 but for the
     few table slots where Adam amplifies rounding noise of a near-zero gradient.
-Not a pytest case: a GPU test process must not start other programs (see tests/conftest.py).
+`python tools/dp_rehearsal.py --single-rank-rccl` runs the same calls against a one-rank RCCL group.
+Not a pytest case: a GPU test process must not start other programs.
 """
 import os
 import sys
@@ -42,7 +43,45 @@ def batches(rank, steps, n, lo):
             for _ in range(steps)]
 
 
+def single_rank_rccl():
+    """One-GPU box: RCCL refuses two ranks on one device, so the calls the data-parallel step makes
+    (asynchronous in-place all-reduces of unaligned slices of the flat gradient, their waits on the
+    compute stream, Adam on each slice behind its reduction) are at least run against a real
+    one-rank RCCL communicator, where a sum over ranks is the identity: the step must give bit for
+    bit what the same step gives without a process group."""
+    import copy
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    net = build("hash").cuda()
+    nets = [net, copy.deepcopy(net)]
+    steps = [trainer.FusedStep(m, m.configure_optimizers(), 1) for m in nets]
+    for st in steps:
+        st.world, st.grad_buckets = 2, 4  # the data-parallel code path (gradients pre-divided by 2)
+    real = parallel.all_reduce_async
+    calls = [0]
+
+    def through_rccl(flat):
+        calls[0] += 1
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    for x, y in batches(0, 4, 20001, 0.0):
+        parallel.all_reduce_async = through_rccl
+        steps[0].train_step(x.cuda(), y.cuda())
+        parallel.all_reduce_async = real          # no group of > 1 ranks: returns None
+        steps[1].train_step(x.cuda(), y.cuda())
+    parallel.barrier()
+    torch.cuda.synchronize()
+    assert calls[0] == 4 * 5, calls
+    assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+    print(f"single-rank RCCL: {calls[0]} asynchronous reductions, parameters bit-identical; "
+          f"rccl {torch.cuda.nccl.version()}")
+    dist.destroy_process_group()
+
+
 def main():
+    if "--single-rank-rccl" in sys.argv:
+        return single_rank_rccl()
     rank, world, local = parallel.init()
     assert world > 1, "launch with torchrun, 2 or more ranks"
     torch.cuda.set_device(local)
