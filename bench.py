@@ -32,10 +32,11 @@ WORKLOADS = {
                  lr=5e-3, norm_siren=False),
     "cfg3": dict(shape=(256, 256, 256), model="siren", hidden=256, batch=1 << 20, lr=1e-4,
                  norm_siren=True),
-    # BASELINE config 5's shape, encoder (4-D: 16 corners per level) and protocol on a synthetic
-    # x,y,z,t phantom -- the sample volume does not travel to the GPU box: the even time frames
-    # are trained on (coordinates from the full t grid, reference interp.py:35), PSNR is reported
-    # on the 7 held-out odd frames next to linear interpolation in t (interp.py's baseline)
+    # BASELINE config 5 on its real workload: the reference's sample volume (352 x 352 x 6 x 15,
+    # tests/golden/sample_volume.npz -- int16 voxels + scl_slope, a data fixture), 4-D encoder
+    # (16 corners per level) and the held-out-frame protocol: the even time frames are trained
+    # on (coordinates from the full t grid, reference interp.py:27,35), PSNR is reported on the 7
+    # held-out odd frames next to linear interpolation in t (interp.py's baseline).
     # Per-axis resolutions (the reference's MultiResHashGridV2, selected by tuple arguments as in
     # models.py:691-708): x, y grow as in config 4, z and t keep one grid node per slice / per
     # TRAINED frame on every level, so features are interpolated linearly between trained frames.
@@ -43,8 +44,23 @@ WORKLOADS = {
     # trained frames but 16 dB on the held-out ones, against 44 dB for linear interpolation.)
     "cfg5": dict(shape=(352, 352, 6, 15), model="hash", base=(16, 16, 5, 7),
                  finest=(16 * 1.4 ** 15, 16 * 1.4 ** 15, 5, 7), hidden=128,
-                 batch=1 << 18, lr=5e-3, norm_siren=False, holdout=True),
+                 batch=1 << 18, lr=5e-3, norm_siren=False, holdout=True, sample_volume=True),
 }
+
+
+def load_volume(w, dev):
+    """The workload's volume in HBM: the analytic phantom, or -- config 5 -- the sample volume."""
+    import numpy as np
+    import torch
+    from mri_interpolation_amd import datamodules
+    if not w.get("sample_volume"):
+        return datamodules.phantom_volume(w["shape"], device=dev), "synthetic"
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sample_volume.npz"))
+    meta = json.loads(str(z["meta"]))
+    vol = (z["raw_int16"].astype(np.float64) * meta["scl_slope"] + meta["scl_inter"])
+    assert tuple(vol.shape) == tuple(w["shape"])
+    return torch.from_numpy(vol.astype(np.float32)).to(dev), \
+        "sample_ankle_dyn_mri.nii.gz (the reference's sample volume, committed as a data fixture)"
 
 
 def build_model(w):
@@ -119,6 +135,86 @@ def cpu_baseline(w, name):
                        f"step) of {name} at batch {b} instead of {w['batch']}")
 
 
+def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
+    """Inference throughput of launcher.py's predict / interpolate passes (reference
+    launcher.py:179-222): ordered dense-grid batches of 2^20 coordinates, generated on device,
+    through the forward kernels only.  One step = one batch; rank r predicts its own slab."""
+    import torch
+    from mri_interpolation_amd import datamodules, parallel
+    batch = 1 << 20
+    full = datamodules.MriImage(volume=vol, norm_siren=w["norm_siren"], device=dev)
+    lo, hi = parallel.voxel_range(full.shape, rank, world)
+    loader = datamodules.DeviceLoader(full, batch, shuffle=False, lo=lo, hi=hi, drop_last=True)
+    per_epoch = len(loader)
+    assert per_epoch > 0, "volume smaller than one predict batch"
+    idx = torch.empty(batch, dtype=torch.int64, device=dev)
+    coords = torch.empty(batch, full.dim_in, device=dev)
+    events, k = {}, [0]
+
+    def one_step(sample):
+        b = k[0] % per_epoch
+        k[0] += 1
+        first, n = loader.span(b)
+        step.phase_events = events if sample else None
+        with step._phase("coords"):
+            full.batch(loader.indices(first, n, out=idx), coords, None)
+        with torch.no_grad():
+            return step.forward(coords, train=False)[0]
+
+    for _ in range(args.warmup):
+        one_step(False)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pred = one_step(i % max(1, args.phase_every) == 0)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+    step.phase_events = events
+    phases = step.phase_ms()
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+    dims = [l.weight.shape[1] for l in step.layers] + [step.layers[-1].weight.shape[0]]
+    mac = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    pm = {"mlp_fwd": ("mfma", 2.0 * mac * batch)}
+    if step.encoder is not None:
+        e = step.encoder  # SURVEY.md 8(d), inference: 4 D + L 2^D F 4 (+ 4 for the intensity)
+        pm["hashgrid_fwd"] = ("hbm", float(4 * e.dim + (1 << e.dim) * e.output_dim * 4
+                                           + e.output_dim * 4) * batch)
+    dominant = max((p for p in phases if p in pm), key=lambda p: phases[p])
+    bound, amount = pm[dominant]
+    sec = phases[dominant] * 1e-3
+    roof = dict(bound=bound, achieved=amount / sec / (1e9 if bound == "hbm" else 1e12),
+                peak=HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF,
+                unit="GB/s" if bound == "hbm" else "TFLOP/s")
+    roof.update(frac=roof["achieved"] / roof["peak"],
+                traffic=pmc_traffic(args.workload + "_predict", dominant), kernel=dominant,
+                ms_per_launch=phases[dominant])
+    value = batch * world * args.steps / elapsed
+    result = {"metric": "coord-samples/sec (predict)", "value": value, "unit": "coord-samples/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data_name,
+              "config": {"workload": f"{args.workload} predict: dense grid "
+                                     f"{'x'.join(map(str, full.shape))}, {w['model']}, "
+                                     f"batch {batch} coords per GPU and step",
+                         "global_batch": batch * world,
+                         "params": sum(p.numel() for p in model.parameters()),
+                         "parallelism": f"dp{world} z-slab" if world > 1 else "single GPU"},
+              "roofline": roof, "phases_ms": {p: round(v, 4) for p, v in sorted(phases.items())},
+              "phases_sampled_every": max(1, args.phase_every),
+              "checksum": float(pred.double().sum())}
+    if step.encoder is not None:
+        e = step.encoder
+        per_coord = 4 * e.dim + (1 << e.dim) * e.output_dim * 4 + 4
+        result["step_hbm_frac"] = value / world * per_coord / (HBM_PEAK_GBS * 1e9)
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +236,11 @@ def main():
                          "(0 = one slice); default: FusedStep's")
     ap.add_argument("--opt", action="append", default=[],
                     help="library tuning option name=value (mri_set_option), repeatable")
+    ap.add_argument("--mode", default="train", choices=["train", "predict"],
+                    help="predict: inference throughput of the same model on the dense grid of "
+                         "the volume (launcher.py's predict / interpolate passes), no training")
+    ap.add_argument("--dp-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="gradient exchange of the data-parallel step (FusedStep.dp_mode)")
     ap.add_argument("--grad-buckets", type=int, default=0,
                     help="level groups of the table-gradient kernels (0 = default)")
     args = ap.parse_args()
@@ -161,21 +262,27 @@ def main():
         args.psnr_steps = 2000 if w["model"] == "hash" else 200
 
     # synthetic volume in HBM, this rank's z-slab, on-device batch generation
-    vol = datamodules.phantom_volume(w["shape"], device=dev)
+    vol, data_name = load_volume(w, dev)
     ds = datamodules.MriImage(volume=vol, norm_siren=w["norm_siren"], device=dev,
                               frames=slice(0, None, 2) if w.get("holdout") else None)
     lo, hi = parallel.voxel_range(ds.shape, rank, world)
+    # several ranks: the same number of full batches on every rank (slabs may differ in size)
     loader = datamodules.DeviceLoader(ds, w["batch"], shuffle=True, lo=lo, hi=hi, drop_last=True,
-                                      seed=1337 + rank)
+                                      seed=1337 + rank,
+                                      steps=datamodules.sharded_steps(ds.shape, w["batch"], world)
+                                      if world > 1 else None)
     model = build_model(w).to(dev)
     opt = model.configure_optimizers()
     step = trainer.FusedStep(model, opt, world)
     step.bwd_method = args.bwd_method
+    step.dp_mode = args.dp_mode
     if args.grad_buckets:
         step.grad_buckets = args.grad_buckets
     if args.split is not None:
         step.split_fraction = args.split
     n_params = sum(p.numel() for p in model.parameters())
+    if args.mode == "predict":
+        return run_predict(args, w, vol, step, model, rank, world, dev, data_name)
     counter = [0]
     events = {}
     sampling = [False]
@@ -243,9 +350,14 @@ def main():
                 if linear is not None:
                     psnr["heldout_linear_interp_db"] = trainer.psnr(linear.reshape(-1, 1),
                                                                     odd.pixels)
+    dist_info = None
     if world > 1:  # leave the process group together (rank 0 was busy with the PSNR pass)
+        import torch.distributed as dist
+        dist_info = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
+                         rccl=".".join(map(str, torch.cuda.nccl.version()))
+                         if dist.get_backend() == "nccl" else None)
         parallel.barrier()
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
     if rank != 0:
         return
 
@@ -266,19 +378,31 @@ def main():
         "metric": "coord-samples/sec (train)", "value": value, "unit": "coord-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} analytic "
-                               f"phantom, {w['model']}, batch {w['batch']} coords per GPU"
+        "data": data_name,
+        "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} "
+                               f"{'sample volume' if w.get('sample_volume') else 'analytic phantom'}"
+                               f", {w['model']}, batch {w['batch']} coords per GPU"
                                + (", even frames trained, odd frames held out"
                                   if w.get("holdout") else ""),
                    "global_batch": w["batch"] * world, "params": n_params,
-                   "parallelism": f"dp{world} z-slab" if world > 1 else "single GPU"},
+                   "parallelism": (f"dp{world} z-slab, {args.dp_mode}"
+                                   + (f", {step.grad_buckets} level groups"
+                                      if args.dp_mode == "all_reduce" else ""))
+                   if world > 1 else "single GPU"},
         "roofline": roof,
         "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
         "phases_sampled_every": max(1, args.phase_every),
         "host_queue_ms_per_step": round(host_ms, 4),
         "final_loss": float(loss),
     }
+    if world > 1:  # what the first real multi-GPU run needs to explain itself
+        import torch.distributed as dist
+        result["collectives"] = {
+            "backend": dist_info["backend"], "ranks_seen": dist_info["ranks"],
+            "rccl_version": dist_info["rccl"],
+            "exposed_ms_per_step": round(phases.get("all_reduce", 0.0), 4),
+            "note": "exposed = wait for the reductions + per-group Adam on the compute stream "
+                    "(phases_ms.all_reduce; it contains the Adam launches, phases_ms.adam is absent)"}
     if step.encoder is not None:  # whole-step HBM fraction as north_star defines it
         e = step.encoder
         per_coord = 4 * e.dim + 4 + 2 * (1 << e.dim) * e.output_dim * 4 + 28.0 * n_params / w["batch"]

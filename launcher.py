@@ -39,11 +39,18 @@ def parse_args(argv=None):
     p.add_argument("--lr", type=float)
     p.add_argument("--dim_hidden", type=int)
     p.add_argument("--n_layers", type=int)
+    p.add_argument("--base_resolution", type=str,
+                   help="hash grid: one integer, or one per axis, e.g. 16,16,5,7 (per-axis values "
+                        "select MultiResHashGridV2, as in reference models.py:691-708)")
+    p.add_argument("--finest_resolution", type=str, help="as --base_resolution (floats allowed)")
     p.add_argument("--tiny_mlp", action="store_true",
                    help="HashMLP with the fused ReLU tiny-MLP decoder of hash_config.json")
     p.add_argument("--holdout_odd_frames", action="store_true",
                    help="train on the even frames of the last axis, report PSNR on the odd ones "
                         "(BASELINE config 5 protocol)")
+    p.add_argument("--checkpoint_path", type=str,
+                   help="resume the parameters from a checkpoint (what the reference does through "
+                        "model_cls.load_from_checkpoint when config.checkpoint_path is set)")
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--max_steps", type=int, default=-1)
     p.add_argument("--log_every", type=int, default=50)
@@ -92,7 +99,8 @@ def main(argv=None):
         config.enco_config = cfg.load_json(enco_path)  # reference launcher.py:73-74
     overrides = {k: v for k, v in vars(args).items()
                  if k not in ("synthetic", "tiny_mlp", "out_dir", "max_steps", "log_every",
-                              "enco_config_path", "holdout_odd_frames")}
+                              "enco_config_path", "holdout_odd_frames", "base_resolution",
+                              "finest_resolution")}
     cfg.apply_overrides(config, overrides)
 
     # ---- data ---------------------------------------------------------------------------
@@ -113,13 +121,20 @@ def main(argv=None):
         config.dim_hidden = args.dim_hidden or int(net.get("n_neurons", 128))
         config.n_layers = args.n_layers or int(net.get("n_hidden_layers", 2)) + 1
         config.activation, config.batch_norm, config.final_activation_on = "ReLU", False, False
-    elif wants_hash and not isinstance(config.base_resolution, int) \
+    for name in ("base_resolution", "finest_resolution"):  # explicit grids win over the JSON's
+        if wants_hash and getattr(args, name):
+            setattr(config, name, cfg.parse_resolution(getattr(args, name)))
+    if wants_hash and not isinstance(config.base_resolution, int) \
             and len(config.base_resolution) != config.dim_in:
         raise SystemExit(f"base_resolution {config.base_resolution} does not match the "
-                         f"{config.dim_in}-D volume (SURVEY.md Q7): pass --slice or --tiny_mlp")
+                         f"{config.dim_in}-D volume (SURVEY.md Q7): pass --slice, --tiny_mlp or "
+                         "--base_resolution / --finest_resolution with one value per axis")
     config.norm_siren = config.model_class in ("SirenNet", "ModulatedSirenNet")
 
     model = build_model(config, models).cuda()
+    if config.checkpoint_path:  # reference launcher.py:97-117
+        ckpt = torch.load(config.checkpoint_path, map_location="cuda", weights_only=True)
+        model.load_state_dict(ckpt.get("state_dict", ckpt))
     datamodule = datamodules.MriDataModule(config=config, volume=volume,
                                            norm_siren=config.norm_siren)
     datamodule.prepare_data()
@@ -129,16 +144,19 @@ def main(argv=None):
     if args.holdout_odd_frames:  # train on even frames, coordinates from the full time grid
         even = datamodules.MriImage(volume=volume, norm_siren=config.norm_siren,
                                     frames=slice(0, None, 2))
-        lo, hi = parallel.voxel_range(even.shape, rank, world)
-        train_loader = datamodules.DeviceLoader(even, config.batch_size, shuffle=True, lo=lo,
-                                                hi=hi, seed=config.seed + rank)
+        train_loader = datamodules.sharded_loader(even, config.batch_size, rank, world,
+                                                  seed=config.seed)
 
     # ---- training -------------------------------------------------------------------------
     trainer = Trainer(max_epochs=config.epochs, max_steps=args.max_steps, precision=32,
-                      log_every=args.log_every)
+                      log_every=args.log_every,
+                      accumulate_grad_batches=config.accumulate_grad_batches)
     t0 = time.time()
     trainer.fit(model, train_loader)
     train_seconds = time.time() - t0
+    if world > 1:  # every rank leaves the group together; rank 0 alone writes the artefacts
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 
@@ -152,6 +170,13 @@ def main(argv=None):
         out_dir = os.path.join(base, f"version_{version}")
         config.log = str(version)
     os.makedirs(out_dir, exist_ok=True)
+
+    # Lightning's default checkpoint: lightning_logs/version_N/checkpoints/epoch=E-step=S.ckpt
+    os.makedirs(os.path.join(out_dir, "checkpoints"), exist_ok=True)
+    torch.save(dict(state_dict={k: v.detach().cpu() for k, v in model.state_dict().items()},
+                    epoch=config.epochs - 1, global_step=trainer.global_step),
+               os.path.join(out_dir, "checkpoints",
+                            f"epoch={config.epochs - 1}-step={trainer.global_step}.ckpt"))
 
     pred = torch.concat(trainer.predict(model, test_loader))
     truth = datamodule.dataset.pixels

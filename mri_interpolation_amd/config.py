@@ -115,3 +115,11 @@ def parse_slice(spec: str):
         else:
             out.append(int(tok))
     return tuple(out)
+
+
+def parse_resolution(spec: str):
+    """'16' -> 16 (isotropic grid), '16,16,5,7' -> (16.0, 16.0, 5.0, 7.0) (per-axis grid)."""
+    vals = [float(t) for t in spec.split(",")]
+    if len(vals) == 1:
+        return int(vals[0]) if vals[0] == int(vals[0]) else vals[0]
+    return tuple(vals)

@@ -126,12 +126,23 @@ class DeviceLoader:
     """Iterable of on-device (coords, targets) batches over a voxel range [lo, hi)."""
 
     def __init__(self, dataset: MriImage, batch_size: int, shuffle: bool, lo: int = 0,
-                 hi: Optional[int] = None, seed: int = 1337, drop_last: bool = False):
+                 hi: Optional[int] = None, seed: int = 1337, drop_last: bool = False,
+                 steps: Optional[int] = None):
+        """`steps` fixes the number of batches per epoch and makes EVERY batch `batch_size` rows:
+        the epoch's permutation of [lo, hi) is walked cyclically (a short range wraps around).
+        Data-parallel ranks whose slabs differ in size use it to run the same number of
+        equal-sized steps (mean of equal-sized local means = global mean; no rank leaves the
+        collective early)."""
         self.ds, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.lo, self.hi = lo, len(dataset) if hi is None else hi
         self.seed, self.epoch, self.drop_last = seed, 0, drop_last
+        self.steps = None if steps is None else int(steps)
+        if self.steps is not None and self.hi <= self.lo:
+            raise ValueError("a loader with a fixed step count needs a non-empty voxel range")
 
     def __len__(self):
+        if self.steps is not None:
+            return self.steps
         n = self.hi - self.lo
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
@@ -143,12 +154,17 @@ class DeviceLoader:
         if self.shuffle:
             return ops.sample_indices(self.seed + 7919 * epoch, first, self.lo, self.hi, n,
                                       out=out, device=self.ds.device)
-        idx = torch.arange(self.lo + first, self.lo + first + n, device=self.ds.device)
+        idx = torch.arange(first, first + n, device=self.ds.device)
+        if self.steps is not None:
+            idx = idx % (self.hi - self.lo)
+        idx = idx + self.lo
         return idx if out is None else out.copy_(idx)
 
     def span(self, b: int):
-        """(first voxel of batch b within [lo, hi), its size)."""
+        """(position of batch b's first voxel in the epoch's permutation of [lo, hi), its size)."""
         first = b * self.batch_size
+        if self.steps is not None:  # cyclic walk: always a full batch
+            return first, self.batch_size
         return first, min(self.batch_size, self.hi - self.lo - first)
 
     def batches(self, n_batches: Optional[int] = None):
@@ -170,6 +186,26 @@ class DeviceLoader:
 
     def __iter__(self):
         return self.batches()
+
+
+def sharded_steps(shape, batch_size: int, world: int) -> int:
+    """Batches per epoch of a data-parallel run: what the LARGEST slab needs, so that every voxel
+    is visited at least once per epoch (slabs differ whenever the slow axis does not divide by
+    the world size; the reference's single loader rounds up the same way, datamodules.py:198)."""
+    longest = max(hi - lo for lo, hi in (parallel.voxel_range(shape, r, world)
+                                         for r in range(world)))
+    return -(-longest // int(batch_size))
+
+
+def sharded_loader(dataset: MriImage, batch_size: int, rank: int = 0, world: int = 1,
+                   seed: int = 1337) -> DeviceLoader:
+    """Shuffled training loader over `rank`'s slab.  One process: the reference's loader (last
+    batch of an epoch may be short).  Several: every rank runs sharded_steps() batches of exactly
+    `batch_size` rows per epoch, shorter slabs wrapping around their permutation."""
+    lo, hi = parallel.voxel_range(dataset.shape, rank, world)
+    steps = sharded_steps(dataset.shape, batch_size, world) if world > 1 else None
+    return DeviceLoader(dataset, batch_size, shuffle=True, lo=lo, hi=hi, seed=seed + rank,
+                        steps=steps)
 
 
 class BatchPipeline:
@@ -261,9 +297,8 @@ class MriDataModule:
 
     def train_dataloader(self, rank: int = 0, world: int = 1) -> DeviceLoader:
         """Shuffled loader over this rank's slab of the volume (whole volume for world 1)."""
-        lo, hi = parallel.voxel_range(self.train_ds.shape, rank, world)
-        return DeviceLoader(self.train_ds, self.config.batch_size, shuffle=True, lo=lo, hi=hi,
-                            seed=getattr(self.config, "seed", 1337) + rank)
+        return sharded_loader(self.train_ds, self.config.batch_size, rank, world,
+                              seed=getattr(self.config, "seed", 1337))
 
     def val_dataloader(self) -> DeviceLoader:
         return DeviceLoader(self.val_ds, self.config.batch_size, shuffle=False)

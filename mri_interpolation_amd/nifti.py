@@ -62,8 +62,10 @@ def load(path) -> np.ndarray:
     return (data.astype(np.float64) * slope + inter).astype(np.float32)
 
 
-def save(array: np.ndarray, path, affine=None):
-    """Write `array` with an identity affine unless one is given."""
+def save(array: np.ndarray, path, affine=None, scl_slope: float = 1.0, scl_inter: float = 0.0):
+    """Write `array` with an identity affine unless one is given.  `scl_slope` / `scl_inter` go
+    into the header as they are (the stored voxels are NOT rescaled): integer voxels plus a slope
+    is how scanners -- and the reference's sample volume -- store intensities."""
     arr = np.asarray(array)
     if arr.dtype.name not in _CODES:
         arr = arr.astype(np.float32)
@@ -77,7 +79,7 @@ def save(array: np.ndarray, path, affine=None):
     struct.pack_into("<2h", hdr, 70, _CODES[arr.dtype.name], arr.dtype.itemsize * 8)
     struct.pack_into("<8f", hdr, 76, 1.0, *([1.0] * 7))      # pixdim
     struct.pack_into("<f", hdr, 108, 352.0)                   # vox_offset
-    struct.pack_into("<2f", hdr, 112, 1.0, 0.0)               # scl_slope, scl_inter
+    struct.pack_into("<2f", hdr, 112, float(scl_slope), float(scl_inter))
     struct.pack_into("<h", hdr, 254, 2)                       # sform_code = aligned
     struct.pack_into("<4f", hdr, 280, *aff[0])
     struct.pack_into("<4f", hdr, 296, *aff[1])

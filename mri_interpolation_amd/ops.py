@@ -100,24 +100,37 @@ def hashgrid_forward(desc: GridDesc, x: torch.Tensor, table: torch.Tensor,
 _bwd_workspace = {}  # device index -> scratch (the library clears what it needs per call)
 
 
-def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
+def backward_workspace_bytes(desc: GridDesc, n: int) -> int:
     need = _lib.load().mri_hashgrid_backward_workspace_bytes(C.byref(desc), n)
     if need < 0:
         _lib.check(-1, "mri_hashgrid_backward_workspace_bytes")
+    return int(need)
+
+
+def backward_workspace(desc: GridDesc, n: int, device) -> torch.Tensor:
+    """Process-wide scratch of the module / autograd path (FusedStep owns its own buffer).  It
+    only ever grows; before a larger one replaces it the device is synchronised, so no kernel of
+    any stream can still be using the buffer that goes back to the allocator."""
+    need = backward_workspace_bytes(desc, n)
     ws = _bwd_workspace.get(device.index)
     if ws is None or ws.numel() * 8 < need:
+        if ws is not None:
+            torch.cuda.synchronize(device)
         ws = torch.empty((need + 7) // 8, dtype=torch.int64, device=device)
         _bwd_workspace[device.index] = ws
     return ws
 
 
-def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, stream=None):
+def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, stream=None,
+                              ws: Optional[torch.Tensor] = None):
     """First stage of the binned backward (record counts per table slice): needs only `x`, so
     it can be queued on a side stream while the forward pass runs.  Follow with
-    hashgrid_backward(..., prepared=True)."""
+    hashgrid_backward(..., prepared=True) on the same workspace `ws` (int64 tensor of at least
+    backward_workspace_bytes(); default: the process-wide one)."""
     _gpu(x)
     n = x.shape[0]
-    ws = backward_workspace(desc, n, x.device)
+    if ws is None:
+        ws = backward_workspace(desc, n, x.device)
     st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
     _lib.call("mri_hashgrid_backward_prepare", C.byref(desc), _ptr(x), n, method, _ptr(ws),
               ws.numel() * 8, st)
@@ -126,7 +139,7 @@ def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, 
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                       d_table: torch.Tensor, feature_major: bool = False, method: int = 0,
                       prepared: bool = False, overwrite: bool = False,
-                      level_mask: Optional[int] = None):
+                      level_mask: Optional[int] = None, ws: Optional[torch.Tensor] = None):
     """d_table += scatter of d_out (or d_table = ..., with overwrite=True); `level_mask`
     restricts the call to the levels whose bit is set (one level group of a bucketed,
     data-parallel backward)."""
@@ -136,7 +149,10 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
     if not d_out.is_contiguous():
         d_out = d_out.contiguous()
     sl, sr, sf = _enc_strides(desc, n, feature_major)
-    ws = backward_workspace(desc, n, x.device) if method != 1 else None
+    if method == 1:
+        ws = None
+    elif ws is None:
+        ws = backward_workspace(desc, n, x.device)
     flags = (method | (_lib.BWD_PREPARED if prepared else 0)
              | (_lib.BWD_OVERWRITE if overwrite else 0))
     if level_mask is None:
@@ -355,6 +371,8 @@ def _tiny_workspace(k_in, hidden, n, device):
     need = _lib.load().mri_tiny_mlp_workspace_bytes(k_in, hidden, n)
     ws = _mlp_workspace.get(device.index)
     if ws is None or ws.numel() * 4 < need:
+        if ws is not None:  # may still be in use on another stream: see backward_workspace()
+            torch.cuda.synchronize(device)
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         _mlp_workspace[device.index] = ws
     return ws

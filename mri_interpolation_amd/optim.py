@@ -15,6 +15,7 @@ import torch
 from . import ops
 
 _ALIGN = 4  # floats (16 B): keeps every parameter's base aligned for float4 access
+_PAD = 256  # floats: allocation granule, see FlatBuffers.capacity
 
 
 class FlatBuffers:
@@ -35,10 +36,15 @@ class FlatBuffers:
             self.offsets.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = total
-        self.param = torch.zeros(total, device=dev)
-        self.grad = torch.zeros(total, device=dev)
-        self.exp_avg = torch.zeros(total, device=dev)
-        self.exp_avg_sq = torch.zeros(total, device=dev)
+        # the allocation is padded (zeros: Adam leaves them zero) so that it divides evenly,
+        # in float4 units, over any power-of-two number of ranks up to 64 (reduce-scatter shards)
+        self.capacity = (total + _PAD - 1) // _PAD * _PAD
+        self._param_all = torch.zeros(self.capacity, device=dev)
+        self._grad_all = torch.zeros(self.capacity, device=dev)
+        self._exp_avg_all = torch.zeros(self.capacity, device=dev)
+        self._exp_avg_sq_all = torch.zeros(self.capacity, device=dev)
+        self.param, self.grad = self._param_all[:total], self._grad_all[:total]
+        self.exp_avg, self.exp_avg_sq = self._exp_avg_all[:total], self._exp_avg_sq_all[:total]
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 n = p.numel()
@@ -101,6 +107,15 @@ class Adam:
     def step(self):
         self.begin_step()
         self.step_range(0, self.flatten().numel)
+
+    @torch.no_grad()
+    def step_shard(self, lo: int, hi: int):
+        """step_range over the PADDED buffers (reduce-scatter shards are cut there)."""
+        flat = self.flatten()
+        lr = self.param_groups[0]["lr"]
+        ops.adam_step(flat._param_all[lo:hi], flat._grad_all[lo:hi], flat._exp_avg_all[lo:hi],
+                      flat._exp_avg_sq_all[lo:hi], lr, self.betas[0], self.betas[1], self.eps,
+                      self.step_count, self.grad_scale)
 
     def state_dict(self):
         f = self.flatten()

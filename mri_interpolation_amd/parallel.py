@@ -95,6 +95,42 @@ def all_reduce_async(flat: torch.Tensor):
     return None
 
 
+def shard_range(numel: int, rank: int, world: int):
+    """[lo, hi) of a flat buffer of `numel` elements (a multiple of `world`) owned by `rank`."""
+    if numel % world:
+        raise ValueError(f"flat buffer of {numel} elements does not divide over {world} ranks")
+    per = numel // world
+    return rank * per, (rank + 1) * per
+
+
+def reduce_scatter_sum(flat: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Sum `flat` over ranks, leaving this rank's shard (shard_range) reduced IN PLACE in `flat`
+    and returning that view; the other shards of `flat` hold garbage afterwards.  RCCL:
+    reduce_scatter (each rank receives 1/world of the bytes an all-reduce moves to it); gloo
+    has no reduce_scatter, so the CPU rehearsal all-reduces and keeps the shard."""
+    lo, hi = shard_range(flat.numel(), rank, world)
+    shard = flat[lo:hi]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return shard
+
+
+def all_gather_shards(flat: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Every rank contributes its shard of `flat` (in place) and receives all the others."""
+    lo, hi = shard_range(flat.numel(), rank, world)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(flat, flat[lo:hi])
+        else:
+            parts = [torch.empty_like(flat[lo:hi]) for _ in range(world)]
+            dist.all_gather(parts, flat[lo:hi].clone())
+            flat.copy_(torch.cat(parts))
+    return flat
+
+
 def wait_all(handles):
     """Make the current stream (or the host, for gloo) wait for the pending reductions."""
     for h in handles:

@@ -90,11 +90,20 @@ class FusedStep:
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
         self.grad_buckets = 1 if world == 1 else 4
         self._bucket_cache = None
+        # "all_reduce": level-group all-reduces overlapped with the table-gradient kernels, every
+        # rank steps the whole buffer.  "reduce_scatter": ONE reduce-scatter of the flat gradient,
+        # each rank Adam-steps its 1/world shard (7/8 less optimiser traffic at 8 ranks), ONE
+        # all-gather of the parameters -- same bytes on the links, but the all-gather sits between
+        # Adam and the next forward pass instead of beside the gradient kernels (DESIGN.md
+        # section 6); kept selectable so both can be timed on a real node.
+        self.dp_mode = "all_reduce"
+        self.rank = parallel.env_world()[0] if world > 1 else 0
         # Single launch of the table gradient: its counting stage depends on the coordinates
         # only, so it is queued on a side stream and overlaps the forward pass / decoder.
         self.overlap_count = True
         self._side = None
         self._counted = False
+        self._bwd_ws = None  # this step's own scratch of the table gradient, see _hash_workspace
         # Fused decoder, optional: cut the batch in two slices and run the encoder of the second
         # on its own stream beside the decoder kernel of the first (the decoder leaves the VALU
         # and the texture path idle, the encoder needs no LDS).  Measured at BASELINE config 4:
@@ -188,57 +197,58 @@ class FusedStep:
                 feature_major = False
         return x, ws
 
-    def _level_buckets(self):
-        """[(level mask, flat-gradient slice)] in execution order for the current bucket count.
+    def _hash_workspace(self, n: int):
+        """Scratch of the table-gradient kernels, owned by this FusedStep (two models in one
+        process never share it).  It is used on the main AND the side stream; when a larger batch
+        needs a larger buffer, both streams are drained before the old one goes back to the
+        allocator."""
+        need = ops.backward_workspace_bytes(self.encoder.desc, n)
+        if self._bwd_ws is None or self._bwd_ws.numel() * 8 < need:
+            if self._bwd_ws is not None:
+                torch.cuda.current_stream().synchronize()
+                if self._side is not None:
+                    self._side.synchronize()
+            self._bwd_ws = torch.empty((need + 7) // 8, dtype=torch.int64,
+                                       device=self.flat.param.device)
+        return self._bwd_ws
 
-        Every level costs the same to compute (same number of corners) but its all-reduce costs
-        its table size, and only the LAST group's reduction cannot hide behind later compute.  So
-        the full-size (hashed) levels are cut into grad_buckets - 1 contiguous groups that run
-        first, finest first, and the coarse levels -- a few per cent of the bytes -- go last."""
+    def _level_buckets(self):
+        """[(level mask, flat-gradient slice)] in execution order for the current bucket count
+        (see level_group_ranges)."""
         enc = self.encoder
         if self._bucket_cache is not None and self._bucket_cache[0] == self.grad_buckets:
             return self._bucket_cache[1]
-        sizes, n_levels = list(enc.sizes), enc.n_levels
-        groups = max(1, min(self.grad_buckets, n_levels))
-        first_full = n_levels
-        while first_full > 0 and sizes[first_full - 1] == max(sizes):
-            first_full -= 1
-        if groups >= 2 and 0 < first_full and n_levels - first_full >= groups - 1:
-            k = groups - 1
-            cuts = [first_full + round(g * (n_levels - first_full) / k) for g in range(k + 1)]
-            ranges = [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1] + [(0, first_full)]
-        else:
-            cuts = [round(g * n_levels / groups) for g in range(groups + 1)]
-            ranges = [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1]
         table_off = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
                                            if q is enc.table)]
-        f = enc.n_features_per_level
-        out = []
-        for lo, hi in ranges:
-            row_lo, row_hi = enc._row_span(lo)[0], enc._row_span(hi - 1)[1]
-            mask = sum(1 << l for l in range(lo, hi))
-            out.append((mask, self.flat.grad[table_off + row_lo * f:table_off + row_hi * f]))
+        out = [(mask, self.flat.grad[lo:hi])
+               for mask, lo, hi in gradient_group_slices(list(enc.sizes),
+                                                         enc.n_features_per_level, table_off,
+                                                         self.flat.numel, self.grad_buckets)
+               if mask is not None]
         self._bucket_cache = (self.grad_buckets, out)
         return out
 
-    def _hash_backward(self, coords, d_enc, overwrite=False):
-        """Table gradient; with several ranks, reduce each finished level group right away."""
+    def _hash_backward(self, coords, d_enc, overwrite=False, reduce=True):
+        """Table gradient; with several ranks, reduce each finished level group right away
+        (`reduce=False`: a micro-batch of an accumulation group that does not step)."""
         enc = self.encoder
         if self._counted:
             torch.cuda.current_stream().wait_stream(self._side)
         counted, self._counted = self._counted, False
-        if self.grad_buckets <= 1:
+        ws = self._hash_workspace(coords.shape[0]) if self.bwd_method != 1 else None
+        if self.grad_buckets <= 1 or not reduce or self.dp_mode == "reduce_scatter":
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
-                                  method=self.bwd_method, prepared=counted, overwrite=overwrite)
+                                  method=self.bwd_method, prepared=counted, overwrite=overwrite,
+                                  ws=ws)
             return []
         if not counted and self.bwd_method != 1:  # one count for all the groups
-            ops.hashgrid_backward_prepare(enc.desc, coords, self.bwd_method)
+            ops.hashgrid_backward_prepare(enc.desc, coords, self.bwd_method, ws=ws)
             counted = True
         pending = []
         for mask, grad_slice in self._level_buckets():
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
                                   method=self.bwd_method, prepared=counted, overwrite=overwrite,
-                                  level_mask=mask)
+                                  level_mask=mask, ws=ws)
             pending.append(self._reduce_async(grad_slice))
         return pending
 
@@ -251,7 +261,8 @@ class FusedStep:
         """Start the reduction of everything in the flat gradient buffer that is not the hash
         table (the decoder's weights: complete as soon as its backward kernels are queued), so
         that it runs beside the table-gradient kernels instead of behind the table's groups."""
-        if self.world <= 1 or self.grad_buckets <= 1 or self.encoder is None:
+        if self.world <= 1 or self.grad_buckets <= 1 or self.encoder is None \
+                or self.dp_mode == "reduce_scatter":
             return []
         f = self.encoder.n_features_per_level
         t0 = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
@@ -272,13 +283,19 @@ class FusedStep:
             return mode, ws["y"][i]
         return mode, None
 
-    def backward(self, coords, target, ws):
-        """Gradients of mean squared error into the flat gradient buffer (zeroed here)."""
+    def backward(self, coords, target, ws, first=True, step=True, divisor=1.0):
+        """Gradients of mean squared error into the flat gradient buffer.  `first`: the buffer
+        is started afresh (zeroed / overwritten), else added to; `step`: this call completes the
+        gradient (data parallel: start its reductions); gradients are scaled by
+        1 / (world * divisor)."""
+        div = float(self.world) * float(divisor)
         if self.use_tiny:
             # every gradient (tables, decoder) and the loss are OVERWRITTEN by the two kernels
             # below: no zeroing pass over the flat gradient buffer
             with self._phase("mlp_fused"):
                 h, n = self._split_rows, coords.shape[0]
+                if not first:
+                    self.loss.zero_()  # the kernels add to it: keep it this batch's loss
                 if h:
                     if self._side2 is None:
                         self._side2 = torch.cuda.Stream(device=coords.device)
@@ -289,27 +306,29 @@ class FusedStep:
                                              feature_major=True, row_offset=h)
                     ops.tiny_mlp_train_slice(ws["enc"], target, 0, h, self.tiny["params"],
                                              self.tiny["grads"], self.loss, ws["d_enc"],
-                                             grad_divisor=float(self.world), overwrite=True)
+                                             grad_divisor=div, overwrite=first)
                     torch.cuda.current_stream().wait_stream(self._side2)  # second slice encoded
                     ops.tiny_mlp_train_slice(ws["enc"], target, h, n - h, self.tiny["params"],
                                              self.tiny["grads"], self.loss, ws["d_enc"],
-                                             grad_divisor=float(self.world), overwrite=False)
+                                             grad_divisor=div, overwrite=False)
                 else:
                     ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"],
                                        self.tiny["grads"], self.loss, d_x=ws["d_enc"],
-                                       grad_divisor=float(self.world), overwrite=True)
-            first = self._reduce_decoder_grads()
+                                       grad_divisor=div, overwrite=first)
+            started = self._reduce_decoder_grads() if step else []
             with self._phase("hashgrid_bwd"):
-                self._pending = first + self._hash_backward(coords, ws["d_enc"], overwrite=True)
+                self._pending = started + self._hash_backward(coords, ws["d_enc"],
+                                                              overwrite=first, reduce=step)
             return
         with self._phase("zero_grad"):
-            self.flat.grad.zero_()
+            if first:
+                self.flat.grad.zero_()
             self.loss.zero_()
         last = len(self.layers) - 1
         pred = ws["y"][last]
         dz = ws["dz"][last]
         with self._phase("loss"):
-            ops.mse_loss(pred, target, self.loss, dz, grad_divisor=float(self.world))
+            ops.mse_loss(pred, target, self.loss, dz, grad_divisor=div)
             mode, g = self._deriv_of(last, ws)
             ops.apply_deriv(dz, mode, g)
         with self._phase("mlp_bwd"):
@@ -327,12 +346,15 @@ class FusedStep:
                     ops.linear_backward_data(dz, l.weight.data, ops.DERIV_NONE, None,
                                              dx=ws["d_enc"], dx_feature_major=True)
         if self.encoder is not None:
-            first = self._reduce_decoder_grads()
+            started = self._reduce_decoder_grads() if step else []
             with self._phase("hashgrid_bwd"):
-                self._pending = first + self._hash_backward(coords, ws["d_enc"])
+                self._pending = started + self._hash_backward(coords, ws["d_enc"], reduce=step)
 
-    def train_step(self, coords, target, side_work=None) -> torch.Tensor:
-        """One optimisation step; returns the (device) loss scalar of this rank's batch.
+    def train_step(self, coords, target, side_work=None, first=True, step=True,
+                   divisor=1.0) -> torch.Tensor:
+        """One batch: forward, loss, backward and -- with `step` -- gradient reduction and Adam;
+        returns the (device) loss scalar of this rank's batch.  Gradient accumulation over k
+        batches: first=True on the first one, step=True on the last, divisor=k on all.
         `side_work()` (e.g. BatchPipeline.produce_next) is queued where it overlaps the step:
         on the side stream behind the counting stage when there is one, else after Adam."""
         if self.encoder is not None and self.overlap_count and self.bwd_method != 1:
@@ -341,7 +363,8 @@ class FusedStep:
             # after the coordinates exist and after the previous step's backward released the
             # workspace (both are earlier work of the current stream)
             self._side.wait_stream(torch.cuda.current_stream())
-            ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side)
+            ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side,
+                                          ws=self._hash_workspace(coords.shape[0]))
             self._counted = True
             if side_work is not None:
                 with torch.cuda.stream(self._side):
@@ -349,12 +372,24 @@ class FusedStep:
                 side_work = None
         _, ws = self.forward(coords, train=True)
         self._pending = []
-        self.backward(coords, target, ws)
-        if self.world > 1 and self._pending:
+        self.backward(coords, target, ws, first, step, divisor)
+        if not step:
+            if side_work is not None:
+                side_work()
+            return self.loss
+        if self.world > 1 and self.dp_mode == "reduce_scatter":
+            with self._phase("all_reduce"):
+                all_grads = self.flat._grad_all
+                parallel.reduce_scatter_sum(all_grads, self.rank, self.world)
+                lo, hi = parallel.shard_range(all_grads.numel(), self.rank, self.world)
+                self.opt.begin_step()
+                self.opt.step_shard(lo, hi)
+                parallel.all_gather_shards(self.flat._param_all, self.rank, self.world)
+        elif self.world > 1 and self._pending:
             # decoder and table level groups are already in flight, in this order; each one is
             # stepped as soon as its sum has landed, beside the reductions still running (Adam is
             # elementwise: the pieces give bit for bit what one launch over the buffer gives)
-            if sum(hi - lo for _, lo, hi in self._pending) != self.flat.numel:
+            if not covers_exactly_once(self._pending, self.flat.numel):
                 raise RuntimeError("gradient groups do not cover the flat buffer exactly once")
             with self._phase("all_reduce"):
                 self.opt.begin_step()
@@ -376,11 +411,32 @@ class Trainer:
     """fit / predict with the subset of `pl.Trainer` the reference launcher uses."""
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
-                 precision: int = 32, log_every: int = 0, distributed: bool = True, **kwargs):
+                 precision: int = 32, log_every: int = 0, distributed: bool = True,
+                 accumulate_grad_batches=None, dp_mode: str = "all_reduce"):
+        """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
+        each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
+        does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
+        scheduler form the reference's config holds, config/base.py:27).  Like Lightning, an
+        epoch's last batch always steps."""
         if precision != 32:
             raise ValueError("the MI355X path is fp32 only (BASELINE parity is 1e-5 fp32)")
+        if accelerator not in ("gpu", "auto", "cuda"):
+            raise ValueError(f"accelerator {accelerator!r}: the hot path runs on the MI355X only")
         self.max_epochs, self.max_steps, self.log_every = max_epochs, max_steps, log_every
-        self.rank, self.world, _ = parallel.env_world() if distributed else (0, 1, 0)
+        self.accumulate = _accumulate_schedule(accumulate_grad_batches)
+        if dp_mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"dp_mode {dp_mode!r} not in ('all_reduce', 'reduce_scatter')")
+        self.dp_mode = dp_mode  # how a data-parallel FusedStep exchanges gradients, see there
+        self.rank, self.world = 0, 1
+        if distributed:
+            rank, world, _ = parallel.env_world()
+            if world > 1 and parallel.world_size() != world:
+                # FusedStep pre-divides gradients by the world size: without a process group
+                # that would silently train on 1/world of the gradient
+                raise RuntimeError(f"WORLD_SIZE={world} but no process group of that size is "
+                                   "initialised: call parallel.init() first (or pass "
+                                   "distributed=False)")
+            self.rank, self.world = rank, world
         self.global_step = 0
         self.history: List[float] = []
         self.throughput: List[float] = []
@@ -395,15 +451,30 @@ class Trainer:
             model.optimizer = opt
         try:
             self.fused = FusedStep(model, opt, self.world)
+            self.fused.dp_mode = self.dp_mode
         except ValueError:
             self.fused = None
             opt.flatten()
         return opt
 
+    def _check_equal_steps(self, loader, device):
+        """Every rank must run the same number of steps (each one holds a collective)."""
+        if self.world <= 1:
+            return
+        n = float(len(loader))
+        hi = parallel.all_reduce_max(n, device)
+        lo = -parallel.all_reduce_max(-n, device)
+        if hi != lo:
+            raise RuntimeError(f"rank {self.rank}: {int(n)} batches per epoch, other ranks "
+                               f"{int(lo)}..{int(hi)}: ranks would leave the gradient all-reduce "
+                               "at different steps; build the loaders with "
+                               "datamodules.sharded_loader() (equal step counts and batch sizes)")
+
     def fit(self, model, train_dataloaders):
         opt = self._prepare(model)
         model.train()
         done = False
+        self._check_equal_steps(train_dataloaders, next(model.parameters()).device)
         # fused path over an on-device loader: ONE double-buffered pipeline for all epochs, the
         # next batch (also the first one of the next epoch) is produced while a step runs
         pipe = None
@@ -415,37 +486,46 @@ class Trainer:
             if pipe is None and hasattr(train_dataloaders, "set_epoch"):
                 train_dataloaders.set_epoch(epoch)
             t0, seen = time.perf_counter(), 0
+            k_acc = _accumulate_at(self.accumulate, epoch)
+            micro = 0  # position inside the current accumulation group
+            n_batches = len(train_dataloaders)
             if pipe is not None:
                 batches = ((b,) + pipe.current() for b in range(len(train_dataloaders)))
             else:
                 batches = ((b, x, y) for b, (x, y) in enumerate(train_dataloaders))
             for batch_idx, x, y in batches:
+                # accumulation group: the first micro-batch starts the gradient, the last one
+                # (or the epoch's last batch) reduces it and steps
+                stepping = micro == k_acc - 1 or batch_idx == n_batches - 1
+                group = dict(first=micro == 0, step=stepping, divisor=float(k_acc))
                 if pipe is not None:
-                    final = (epoch == self.max_epochs - 1
-                             and batch_idx == len(train_dataloaders) - 1) \
-                        or 0 < self.max_steps <= self.global_step + 1
-                    loss = self.fused.train_step(x, y, None if final else pipe.produce_next)
+                    final = (epoch == self.max_epochs - 1 and batch_idx == n_batches - 1) \
+                        or (stepping and 0 < self.max_steps <= self.global_step + 1)
+                    loss = self.fused.train_step(x, y, None if final else pipe.produce_next,
+                                                 **group)
                     if not final:
                         pipe.advance()
                 elif self.fused is not None:
-                    loss = self.fused.train_step(x, y)
+                    loss = self.fused.train_step(x, y, **group)
                 else:
-                    opt.zero_grad()
+                    if micro == 0:
+                        opt.zero_grad()
                     loss = model.training_step((x, y), batch_idx)
-                    if self.world > 1:
-                        loss = loss / self.world
-                    loss.backward()
-                    if self.world > 1:
-                        parallel.all_reduce_sum(opt.flatten().grad)
-                    opt.step()
-                self.global_step += 1
+                    (loss / (self.world * k_acc)).backward()
+                    if stepping:
+                        if self.world > 1:
+                            parallel.all_reduce_sum(opt.flatten().grad)
+                        opt.step()
+                micro = 0 if stepping else micro + 1
+                if stepping:  # as Lightning counts: optimizer steps
+                    self.global_step += 1
                 seen += x.shape[0]
-                if self.log_every and self.global_step % self.log_every == 0:
+                if self.log_every and stepping and self.global_step % self.log_every == 0:
                     self.history.append(float(loss))
                     if self.rank == 0:
                         print(f"epoch {epoch} step {self.global_step} loss {self.history[-1]:.6e}",
                               flush=True)
-                if 0 < self.max_steps <= self.global_step:
+                if stepping and 0 < self.max_steps <= self.global_step:
                     done = True
                     break
             torch.cuda.synchronize()
@@ -475,6 +555,79 @@ class Trainer:
             else:
                 out.append(model.predict_step((x, y), batch_idx))
         return out
+
+
+def level_group_ranges(sizes, groups: int):
+    """Level ranges [(lo, hi)] of a bucketed table gradient, in execution order.
+
+    Every level costs the same to compute (same number of corners) but its all-reduce costs its
+    table size, and only the LAST group's reduction cannot hide behind later compute.  So the
+    full-size (hashed) levels are cut into groups - 1 contiguous groups that run first, finest
+    first, and the coarse levels -- a few per cent of the bytes -- go last."""
+    n_levels = len(sizes)
+    groups = max(1, min(groups, n_levels))
+    first_full = n_levels
+    while first_full > 0 and sizes[first_full - 1] == max(sizes):
+        first_full -= 1
+    if groups >= 2 and 0 < first_full and n_levels - first_full >= groups - 1:
+        k = groups - 1
+        cuts = [first_full + round(g * (n_levels - first_full) / k) for g in range(k + 1)]
+        return [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1] + [(0, first_full)]
+    cuts = [round(g * n_levels / groups) for g in range(groups + 1)]
+    return [(lo, hi) for lo, hi in zip(cuts, cuts[1:])][::-1]
+
+
+def gradient_group_slices(sizes, n_features: int, table_offset: int, flat_numel: int,
+                          groups: int):
+    """[(level mask or None, lo, hi)]: the slices of the flat gradient buffer a data-parallel
+    step reduces, in the order their reductions start -- what is not the hash table first (the
+    decoder's gradients are complete before the table gradient starts), then the level groups.
+    The slices cover [0, flat_numel) exactly once (checked by FusedStep on every step)."""
+    rows = [0]
+    for t in sizes:
+        rows.append(rows[-1] + int(t))
+    t0, t1 = table_offset, table_offset + rows[-1] * n_features
+    out = []
+    if t0 > 0:
+        out.append((None, 0, t0))
+    if t1 < flat_numel:
+        out.append((None, t1, flat_numel))
+    for lo, hi in level_group_ranges(list(sizes), groups):
+        mask = sum(1 << l for l in range(lo, hi))
+        out.append((mask, t0 + rows[lo] * n_features, t0 + rows[hi] * n_features))
+    return out
+
+
+def covers_exactly_once(slices, numel: int) -> bool:
+    spans = sorted((lo, hi) for _, lo, hi in slices)
+    return bool(spans) and spans[0][0] == 0 and spans[-1][1] == numel and \
+        all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all(lo < hi for lo, hi in spans)
+
+
+def _accumulate_schedule(spec):
+    """{first epoch: batches per step}, sorted; None / 1 -> {0: 1}."""
+    if spec is None:
+        return {0: 1}
+    if isinstance(spec, int):
+        sched = {0: spec}
+    else:
+        try:
+            sched = {int(e): int(k) for e, k in dict(spec).items()}
+        except (TypeError, ValueError):
+            raise TypeError(f"accumulate_grad_batches must be an int or a mapping epoch -> int, "
+                            f"got {spec!r}") from None
+    if any(k < 1 for k in sched.values()) or any(e < 0 for e in sched):
+        raise ValueError(f"accumulate_grad_batches {spec!r}: counts must be >= 1, epochs >= 0")
+    sched.setdefault(0, 1)
+    return dict(sorted(sched.items()))
+
+
+def _accumulate_at(sched, epoch: int) -> int:
+    k = 1
+    for e, v in sched.items():
+        if e <= epoch:
+            k = v
+    return k
 
 
 def psnr(pred: torch.Tensor, target: torch.Tensor) -> float:

@@ -174,12 +174,99 @@ def extra_models(encoding, models):
     save("frequency", dict(cases=[[2, 10], [3, 6], [4, 4]]), **arrays)
 
 
+def read_sample_volume():
+    """int16 voxels + scl_slope of the reference's sample NIfTI (a data file, parsed by hand:
+    nibabel is not installed)."""
+    raw = gzip.open(os.path.join(REF, "sample_ankle_dyn_mri.nii.gz")).read()
+    dims = struct.unpack("<8h", raw[40:56])
+    vox_offset = int(struct.unpack("<f", raw[108:112])[0])
+    slope, inter = struct.unpack("<ff", raw[112:120])
+    shape = dims[1:1 + dims[0]]
+    vol = np.frombuffer(raw, dtype="<i2", offset=vox_offset,
+                        count=int(np.prod(shape))).reshape(shape, order="F")
+    return vol, shape, slope, inter
+
+
+def round2_fixtures(encoding, models):
+    """Fixtures added in round 2 (the earlier ones stay byte-identical):
+    O3b the per-axis 4-D encoder BASELINE config 5 trains with; O7b the notebook's HashMLP
+    decoder (Linear -> GELU blocks, no BatchNorm: ReprésentationsImplicites.ipynb cell 37,
+    i.e. models.py:712-739 with the BatchNorm1d / Dropout members skipped); O8b the whole
+    sample volume (config 5's workload)."""
+    fin4 = 16 * 1.4 ** 15
+    kw = dict(n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+              base_resolution=(16, 16, 5, 7), finest_resolution=(fin4, fin4, 5, 7))
+    enc = encoding.MultiResHashGridV2(4, **kw)
+    ctor = dict(cls="MultiResHashGridV2", dim=4,
+                **{k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()})
+    encoder_fixture("enc_v2_cfg5", enc, ctor, 4, 96, seed=len("enc_v2_cfg5"), scale=0.5)
+
+    # ---- O7b: notebook decoder, forward + loss + every gradient + 2 Adam steps ---------------
+    nb = dict(n_levels=8, n_features_per_level=2, log2_hashmap_size=23,
+              base_resolution=(64, 64, 5), finest_resolution=(512, 512, 15))
+    hm = models.HashMLP(dim_in=3, dim_hidden=64, dim_out=1, n_layers=2, lr=5e-3, **nb)
+    sizes = load_tables(hm.encoder, 91, 0.5)
+    params = omlp.linear_init([16, 64, 1], 92)
+    blocks = [nn.Sequential(blk[0], blk[2]) for blk in hm.decoder]  # Linear -> GELU
+    assert all(isinstance(b[0], nn.Linear) and isinstance(b[1], nn.GELU) for b in blocks)
+    with torch.no_grad():
+        for b, (w, bias) in zip(blocks, params):
+            b[0].weight.copy_(w)
+            b[0].bias.copy_(bias)
+    trainable = list(hm.encoder.parameters()) + [q for b in blocks for q in b.parameters()]
+    opt = torch.optim.Adam(trainable, lr=5e-3)
+    arrays = {}
+    for step in range(2):
+        x = detrand.uniform(384 * 3, 930 + step, 0.0, 1.0).reshape(384, 3)
+        y = detrand.uniform(384, 940 + step, 0.0, 1.0).reshape(384, 1)
+        opt.zero_grad()
+        z = hm.encoder(torch.from_numpy(x))
+        for b in blocks:
+            z = b(z)
+        loss = torch.nn.functional.mse_loss(z, torch.from_numpy(y))  # notebook: (y_pred, y)
+        loss.backward()
+        arrays[f"x_{step}"], arrays[f"y_{step}"] = x, y
+        arrays[f"pred_{step}"] = z.detach().numpy().copy()
+        arrays[f"loss_{step}"] = np.float32(loss.item())
+        if step == 0:
+            idx, val = sparse_grads(hm.encoder)
+            for l, (i, v) in enumerate(zip(idx, val)):
+                arrays[f"grad_idx_{l}"], arrays[f"grad_val_{l}"] = i, v.copy()
+            for i, b in enumerate(blocks):
+                arrays[f"gw_{i}"] = b[0].weight.grad.numpy().copy()
+                arrays[f"gb_{i}"] = b[0].bias.grad.numpy().copy()
+        opt.step()
+        for i, b in enumerate(blocks):
+            arrays[f"w_{step}_{i}"] = b[0].weight.detach().numpy().copy()
+            arrays[f"b_{step}_{i}"] = b[0].bias.detach().numpy().copy()
+        # tables after the step: the rows the step touched (Adam moves every touched row)
+        for l, lvl in enumerate(hm.encoder.levels):
+            rows = arrays[f"grad_idx_{l}"]
+            arrays[f"table_{step}_{l}"] = lvl.embedding.weight.detach().numpy()[rows].copy()
+    res = [[float(r) for r in np.atleast_1d(np.asarray(lvl.resolution, dtype=np.float64))]
+           for lvl in hm.encoder.levels]
+    save("hashmlp_gelu_notebook",
+         dict(ctor=dict(dim=3, **{k: (list(v) if isinstance(v, tuple) else v)
+                                  for k, v in nb.items()}),
+              sizes=sizes, resolutions=res, table_seed=91, table_scale=0.5, mlp_seed=92,
+              dims=[16, 64, 1], lr=5e-3, steps=2), **arrays)
+
+    # ---- O8b: the sample volume itself ----------------------------------------------------------
+    vol, shape, slope, inter = read_sample_volume()
+    save("sample_volume", dict(shape=list(shape), scl_slope=slope, scl_inter=inter,
+                               source="sample_ankle_dyn_mri.nii.gz (int16 voxels, F-order file "
+                                      "reshaped to the NIfTI axes x, y, z, t)"),
+         raw_int16=np.ascontiguousarray(vol))
+
+
 def main():
     torch.manual_seed(1337)
     torch.set_num_threads(4)
     encoding, models = import_reference()
     if "--extra-only" in sys.argv:  # leave the existing fixtures untouched
         return extra_models(encoding, models)
+    if "--round2-only" in sys.argv:
+        return round2_fixtures(encoding, models)
 
     # ---- O1: hash ids (encoding.py:69-78) ------------------------------------------------
     arrays, cases = {}, []
@@ -374,6 +461,7 @@ def main():
                                     slice="[:, :, 3, 7]"),
          raw_int16=np.ascontiguousarray(vol[:, :, 3, 7]))
     extra_models(encoding, models)
+    round2_fixtures(encoding, models)
 
 
 if __name__ == "__main__":

@@ -89,3 +89,92 @@ def test_env_world_defaults(monkeypatch):
     assert parallel.env_world() == (0, 1, 0)
     t = torch.ones(4)
     assert parallel.all_reduce_sum(t) is t and parallel.world_size() == 1
+
+
+# ------------------------------------------------------------ the fused step's bucketed reduction
+def _bucket_worker(rank, world, port, out_dir):
+    """Each rank fills a flat gradient buffer laid out like FusedStep's (decoder | tables |
+    decoder tail), reduces it through FusedStep's own slice plan (level groups, asynchronous,
+    in launch order), and -- second form -- through reduce-scatter / all-gather shards."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mri_interpolation_amd import parallel, trainer
+    torch.set_num_threads(1)
+    parallel.init(backend="gloo")
+    sizes = [4096, 10648, 29791, 79507] + [131072] * 6   # config-4-like: coarse, then full levels
+    feats, table_off = 2, 4228                           # the decoder's first layer sits in front
+    numel = table_off + feats * sum(sizes) + 16516
+    g = torch.Generator().manual_seed(7 + rank)
+    mine = torch.randn(numel, generator=g)
+    for groups in (1, 2, 4, 16):
+        plan = trainer.gradient_group_slices(sizes, feats, table_off, numel, groups)
+        assert trainer.covers_exactly_once(plan, numel), groups
+        masks = [m for m, _, _ in plan if m is not None]
+        assert sum(masks) == (1 << len(sizes)) - 1 and len(masks) == min(groups, len(sizes))
+        if groups >= 2:
+            assert masks[-1] & 1 and not masks[0] & 1    # coarse levels last, finest first
+        flat = mine.clone()
+        handles = [parallel.all_reduce_async(flat[lo:hi]) for _, lo, hi in plan]
+        parallel.wait_all(handles)
+        whole = parallel.all_reduce_sum(mine.clone())
+        assert torch.equal(flat, whole), groups          # same bits as ONE reduction
+    # a plan with a hole or an overlap is caught
+    bad = plan[:-1] + [(plan[-1][0], plan[-1][1] + 4, plan[-1][2])]
+    assert not trainer.covers_exactly_once(bad, numel)
+    # reduce-scatter -> shard -> all-gather gives every rank the fully reduced buffer
+    padded = torch.zeros((numel + 255) // 256 * 256)
+    padded[:numel] = mine
+    shard = parallel.reduce_scatter_sum(padded, rank, world)
+    lo, hi = parallel.shard_range(padded.numel(), rank, world)
+    assert torch.equal(shard, whole.new_zeros(padded.numel()).index_copy_(
+        0, torch.arange(numel), whole)[lo:hi])
+    keep = torch.zeros_like(padded)
+    keep[lo:hi] = shard
+    parallel.all_gather_shards(keep, rank, world)
+    assert torch.equal(keep[:numel], whole)
+    np.save(os.path.join(out_dir, f"bucket{rank}.npy"), whole.numpy())
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reduce_through_the_fused_steps_slice_plan(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(tmp_path / f"bucket{r}.npy") for r in range(world))
+    np.testing.assert_array_equal(a, b)
+
+
+def _loader_worker(rank, world, port, out_dir):
+    """Host side of Trainer.fit's data-parallel contract on ranks whose slabs differ in size."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mri_interpolation_amd import datamodules, parallel, trainer
+    parallel.init(backend="gloo")
+
+    class Shape:
+        shape, dim_in, device = (25, 32, 32), 3, "cpu"   # 13 + 12 slices
+
+        def __len__(self):
+            return 25 * 32 * 32
+    tr = trainer.Trainer(max_epochs=1)
+    assert (tr.rank, tr.world) == (rank, world)
+    good = datamodules.sharded_loader(Shape(), 4096, rank, world)
+    tr._check_equal_steps(good, torch.device("cpu"))      # 4 steps of 4096 on both ranks
+    assert len(good) == 4 and {good.span(b)[1] for b in range(4)} == {4096}
+    lo, hi = parallel.voxel_range(Shape.shape, rank, world)
+    naive = datamodules.DeviceLoader(Shape(), 4096, shuffle=True, lo=lo, hi=hi)  # 4 vs 3 batches
+    try:
+        tr._check_equal_steps(naive, torch.device("cpu"))
+        raised = False
+    except RuntimeError as e:
+        raised = "sharded_loader" in str(e)
+    open(os.path.join(out_dir, f"loader{rank}.txt"), "w").write(f"{len(naive)} {raised}")
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_slabs_run_equal_steps_or_fail_loudly(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_loader_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [open(tmp_path / f"loader{r}.txt").read().split() for r in range(world)]
+    assert got == [["4", "True"], ["3", "True"]]

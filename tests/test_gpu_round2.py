@@ -1,0 +1,387 @@
+"""Round-2 parity cases on the MI355X: BASELINE config 5 on its REAL workload (the reference's
+sample volume), reconstructed intensities at full batch size (configs 3 and 4), the notebook's
+Linear -> GELU decoder, gradient accumulation, and the data-parallel step against a real
+(one-rank) RCCL communicator.  Tolerances as in test_gpu_parity.py (conftest.REL_TOL = 1e-5).
+"""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REL_TOL, assert_close, load_golden
+from oracle import data as odata
+from oracle import detrand
+from oracle import hashgrid as ohash
+from oracle import mlp as omlp
+from oracle import train as otrain
+
+pytestmark = pytest.mark.gpu
+
+FIN4 = 16 * 1.4 ** 15
+CFG5_BASE, CFG5_FINEST = (16, 16, 5, 7), (FIN4, FIN4, 5, 7)   # bench.py's config-5 encoder
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from mri_interpolation_amd import _lib, datamodules, encoding, models, nifti, ops, trainer
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    _lib.load()
+    return type("NS", (), dict(lib=_lib, ops=ops, encoding=encoding, models=models, nifti=nifti,
+                               trainer=trainer, datamodules=datamodules))
+
+
+def cuda(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def sample_volume(tmp_path_factory):
+    """The reference's sample volume rebuilt as the file the reference ships: int16 voxels plus
+    scl_slope in a gzipped NIfTI-1 (tests/golden/sample_volume.npz holds the data)."""
+    from mri_interpolation_amd import nifti
+    fx = load_golden("sample_volume")
+    path = str(tmp_path_factory.mktemp("sample") / "sample_ankle_dyn_mri.nii.gz")
+    nifti.save(fx["raw_int16"], path, scl_slope=fx.meta["scl_slope"], scl_inter=fx.meta["scl_inter"])
+    vol = (fx["raw_int16"].astype(np.float64) * fx.meta["scl_slope"]
+           + fx.meta["scl_inter"]).astype(np.float32)
+    return path, vol
+
+
+# ------------------------------------------------------------------------- config 5, real data
+def test_sample_volume_through_nifti_and_mriimage_4d(amd, sample_volume):
+    """nifti.load + MriImage on the 4-D sample (reference datamodules.py:135-166): coordinates
+    and targets of sampled voxels equal the oracle's, bit for bit; so do the even-frame
+    training set's (interp.py:27,35 protocol: coordinates from the FULL time grid)."""
+    path, vol = sample_volume
+    assert amd.nifti.read_header(path)["shape"] == (352, 352, 6, 15)
+    loaded = amd.nifti.load(path)
+    np.testing.assert_array_equal(loaded, vol)
+    ds = amd.datamodules.MriImage(image_path=path)
+    assert ds.shape == (352, 352, 6, 15) and len(ds) == 11151360
+    coords, pix = odata.dataset(vol)
+    idx = torch.from_numpy(detrand.integers(50000, 5, 0, len(ds) - 1).astype(np.int64))
+    idx[:4] = torch.tensor([0, 14, 15, len(ds) - 1])
+    c, p = ds.batch(idx.cuda())
+    assert torch.equal(c.cpu(), coords[idx]) and torch.equal(p.cpu(), pix[idx])
+    even = amd.datamodules.MriImage(image_path=path, frames=slice(0, None, 2))
+    assert even.shape == (352, 352, 6, 8) and len(even) == 5947392       # SURVEY.md 8(d) cfg 5
+    want_c = coords.view(352, 352, 6, 15, 4)[..., ::2, :].reshape(-1, 4)
+    want_p = pix.view(352, 352, 6, 15)[..., ::2].reshape(-1, 1)
+    jdx = torch.from_numpy(detrand.integers(50000, 6, 0, len(even) - 1).astype(np.int64))
+    c, p = even.batch(jdx.cuda())
+    assert torch.equal(c.cpu(), want_c[jdx]) and torch.equal(p.cpu(), want_p[jdx])
+    # a shuffled epoch over the even frames visits every voxel exactly once
+    loader = amd.datamodules.DeviceLoader(even, 1 << 18, shuffle=True, seed=1337)
+    seen = torch.zeros(len(even), dtype=torch.int32, device="cuda")
+    for b in range(len(loader)):
+        first, n = loader.span(b)
+        seen.index_add_(0, loader.indices(first, n), torch.ones(n, dtype=torch.int32, device="cuda"))
+    assert int(seen.min()) == 1 and int(seen.max()) == 1
+
+
+def test_config5_encoder_golden(amd):
+    """The encoder config 5 trains with (per-axis MultiResHashGridV2, 4-D: 16 corners) against the
+    reference's outputs and table gradients, all three backward methods."""
+    fx = load_golden("enc_v2_cfg5")
+    enc = amd.encoding.MultiResHashGridV2(4, n_levels=16, n_features_per_level=2,
+                                          log2_hashmap_size=19, base_resolution=CFG5_BASE,
+                                          finest_resolution=CFG5_FINEST)
+    assert enc.sizes == fx.meta["sizes"]
+    tabs = ohash.init_tables(enc.sizes, 2, fx.meta["table_seed"], fx.meta["table_scale"])
+    with torch.no_grad():
+        enc.table.copy_(torch.cat(tabs))
+    enc = enc.cuda()
+    x = cuda(fx["x"])
+    with torch.no_grad():
+        assert_close(enc(x).cpu().numpy(), fx["out"], 1e-6, "forward")
+    for method in (0, 1, 2):
+        g = torch.zeros_like(enc.table.data)
+        amd.ops.hashgrid_backward(enc.desc, x, cuda(fx["d_out"]), g, method=method)
+        g = g.cpu().numpy()
+        for l in range(16):
+            lo, hi = enc._row_span(l)
+            nz = np.nonzero(np.abs(g[lo:hi]).sum(1))[0]
+            np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
+            assert_close(g[lo:hi][nz], fx[f"grad_val_{l}"], REL_TOL, f"method {method} level {l}")
+
+
+def test_config5_protocol_on_the_sample_volume(amd, sample_volume, tmp_path):
+    """BASELINE config 5 through launcher.main on the REAL volume: hash encoder + tiny MLP trained
+    on the 8 even frames (coordinates from the full time grid), PSNR on the 7 held-out odd frames
+    next to the linear-in-t baseline of interp.py, NIfTI artefacts of the full 4-D prediction."""
+    import interp
+    import launcher
+    path, vol = sample_volume
+    out = str(tmp_path / "run")
+    launcher.main(["--model_class", "HashMLP", "--tiny_mlp", "--image_path", path,
+                   "--base_resolution", ",".join(str(v) for v in CFG5_BASE),
+                   "--finest_resolution", ",".join(repr(v) for v in CFG5_FINEST),
+                   "--batch_size", str(1 << 18), "--epochs", "30", "--holdout_odd_frames",
+                   "--out_dir", out, "--log_every", "0"])
+    txt = open(os.path.join(out, "config.txt")).read()
+    field = lambda k: float([l for l in txt.splitlines() if l.startswith(k)][0].split(":")[1])  # noqa: E731
+    held, fit = field("psnr_heldout_db"), field("psnr_db")
+    # the non-neural baseline on the same normalisation ((v - min) / (max - min), min = 0)
+    norm = vol / vol.max()
+    base = interp.psnr(interp.interpolate_even_frames(norm)[..., 1::2], norm[..., 1::2])
+    print(f"config 5 on the sample volume: PSNR all frames {fit:.2f} dB, held-out odd frames "
+          f"{held:.2f} dB, linear interpolation in t {base:.2f} dB")
+    pred = amd.nifti.load(os.path.join(out, "pred.nii.gz"))
+    assert pred.shape == (352, 352, 6, 15) and np.isfinite(pred).all()
+    assert os.path.exists(os.path.join(out, "checkpoints"))
+    assert held > base - 3.0, (held, base)   # 690 steps: within 3 dB of the linear baseline
+    assert fit > 25.0, fit
+
+
+# ------------------------------------------------------------ intensities at full batch size
+def test_full_size_cfg4_intensities_match_oracle(amd):
+    """north_star's tolerance is on RECONSTRUCTED INTENSITIES: all 2^18 predictions of the
+    headline workload (config 4: L16 F2 T2^19 growth 1.4, MLP 32-128-128-1) against the oracle,
+    through the training-step kernel (its `y` output) and through the inference kernel."""
+    n = 1 << 18
+    model = otrain.HashMlpModel(3, 16, 2, 19, 16, FIN4, [128, 128], seed=11, table_scale=0.1)
+    net = amd.models.HashMLP(3, 16, 2, 19, 16, FIN4, dim_hidden=128, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False)
+    with torch.no_grad():
+        net.encoder.table.copy_(torch.cat(model.tables))
+        for blk, (w, b) in zip(net.decoder, model.mlp):
+            blk[0].weight.copy_(w)
+            blk[0].bias.copy_(b)
+    net = net.cuda()
+    x = torch.from_numpy(detrand.uniform(n * 3, 43, 0.0, 1.0).reshape(n, 3))
+    want = model.forward(x).numpy()
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    assert step.use_tiny
+    with torch.no_grad():
+        infer = step.forward(x.cuda(), train=False)[0].cpu().numpy()
+    assert_close(infer, want, REL_TOL, "inference kernel, 2^18 intensities")
+    # the training kernel's own predictions (optional y output of mri_tiny_mlp_train)
+    _, ws = step.forward(x.cuda(), train=True)
+    y_train = torch.empty(n, 1, device="cuda")
+    amd.ops.tiny_mlp_train(ws["enc"], torch.zeros(n, 1, device="cuda"), step.tiny["params"],
+                           step.tiny["grads"], step.loss, d_x=ws["d_enc"], y=y_train,
+                           overwrite=True)
+    assert_close(y_train.cpu().numpy(), want, REL_TOL, "training kernel, 2^18 intensities")
+    with torch.no_grad():
+        assert_close(net(x.cuda()).cpu().numpy(), want, REL_TOL, "module forward")
+
+
+def test_full_size_cfg3_siren_intensities_and_step(amd):
+    """BASELINE config 3 at its real batch (SIREN 3-256x5-1, B = 2^20): predictions of a
+    4,096-row sample and the loss against the oracle, then one whole step must move every layer
+    the way the oracle's step does (sampled through the first layer's weights, whose gradient
+    the oracle computes from the same 2^20 rows)."""
+    n, lr = 1 << 20, 1e-4
+    model = otrain.SirenModel(3, 256, 1, 5, seed=45)
+    net = amd.models.SirenNet(3, 256, 1, 5, lr=lr)
+    with torch.no_grad():
+        for layer, (w, b) in zip(list(net.layers) + [net.last_layer], model.params):
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+    net = net.cuda()
+    x = torch.from_numpy(detrand.uniform(n * 3, 46, -1.0, 1.0).reshape(n, 3))
+    y = torch.sin(3 * x[:, :1]) * torch.cos(2 * x[:, 1:2]) * 0.5
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    xg, yg = x.cuda(), y.cuda()
+    pred, ws = step.forward(xg, train=True)
+    rows = torch.from_numpy(detrand.integers(4096, 47, 0, n - 1).astype(np.int64))
+    want_rows = model.forward(x[rows])
+    assert_close(pred[rows.cuda()].cpu().numpy(), want_rows.numpy(), REL_TOL, "sampled intensities")
+    step.backward(xg, yg, ws)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    want_loss, want_pred, grads = otrain.loss_and_grads(model, x, y)
+    assert abs(float(step.loss) - float(want_loss)) <= REL_TOL * float(want_loss)
+    assert_close(pred.cpu().numpy(), want_pred.numpy(), REL_TOL, "all 2^20 intensities")
+    # gradients are sums of 2^20 terms: f32 summation order limits agreement to ~1e-4 where
+    # terms cancel; 5e-5 of the tensor's maximum holds for every layer (measured 1e-6 .. 2e-5)
+    layers = list(net.layers) + [net.last_layer]
+    for i, layer in enumerate(layers):
+        assert_close(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), 5e-5, f"gw{i}")
+        assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), 5e-5, f"gb{i}")
+
+
+# ----------------------------------------------------------------- notebook Linear -> GELU decoder
+@pytest.mark.parametrize("path", ["module", "fused"])
+def test_hashmlp_gelu_notebook_decoder(amd, path):
+    """SURVEY.md 8(f) row 3, second half: HashMLP(batch_norm=False, activation=nn.GELU) is the
+    notebook's decoder (cell 37; models.py:712-739 without BatchNorm).  Forward, loss, every
+    gradient and two Adam steps against the reference modules' outputs, on the autograd module
+    path and on the fused kernel chain."""
+    fx = load_golden("hashmlp_gelu_notebook")
+    m, c = fx.meta, fx.meta["ctor"]
+    net = amd.models.HashMLP(dim_in=3, n_levels=c["n_levels"],
+                             n_features_per_level=c["n_features_per_level"],
+                             log2_hashmap_size=c["log2_hashmap_size"],
+                             base_resolution=tuple(c["base_resolution"]),
+                             finest_resolution=tuple(c["finest_resolution"]), dim_hidden=64,
+                             dim_out=1, n_layers=2, activation=torch.nn.GELU, batch_norm=False,
+                             lr=m["lr"])
+    assert net.encoder.sizes == m["sizes"]
+    tabs = ohash.init_tables(net.encoder.sizes, 2, m["table_seed"], m["table_scale"])
+    with torch.no_grad():
+        net.encoder.table.copy_(torch.cat(tabs))
+        for blk, (w, b) in zip(net.decoder, omlp.linear_init(m["dims"], m["mlp_seed"])):
+            blk[0].weight.copy_(w)
+            blk[0].bias.copy_(b)
+    net = net.cuda()
+    opt = net.configure_optimizers()
+    step = amd.trainer.FusedStep(net, opt) if path == "fused" else None
+    assert step is None or (not step.use_tiny and len(step.layers) == 2)
+    for s in range(m["steps"]):
+        x, y = cuda(fx[f"x_{s}"]), cuda(fx[f"y_{s}"])
+        if step is not None:
+            pred, ws = step.forward(x, train=True)
+            pred = pred.clone()
+            step.backward(x, y, ws)
+            loss = float(step.loss)
+        else:
+            opt.zero_grad()
+            pred = net(x)
+            l = net.criterion(y, pred)
+            l.backward()
+            loss = float(l)
+        assert_close(pred.detach().cpu().numpy(), fx[f"pred_{s}"], REL_TOL, f"pred step {s}")
+        assert abs(loss - float(fx[f"loss_{s}"])) <= REL_TOL * float(fx[f"loss_{s}"])
+        if s == 0:
+            g = net.encoder.table.grad.cpu().numpy()
+            for l in range(c["n_levels"]):
+                lo, hi = net.encoder._row_span(l)
+                nz = np.nonzero(np.abs(g[lo:hi]).sum(1))[0]
+                np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
+                assert_close(g[lo:hi][nz], fx[f"grad_val_{l}"], REL_TOL, f"table grad {l}")
+            for i, blk in enumerate(net.decoder):
+                assert_close(blk[0].weight.grad.cpu().numpy(), fx[f"gw_{i}"], REL_TOL, f"gw{i}")
+                assert_close(blk[0].bias.grad.cpu().numpy(), fx[f"gb_{i}"], REL_TOL, f"gb{i}")
+        opt.step()
+        for i, blk in enumerate(net.decoder):
+            assert_close(blk[0].weight.detach().cpu().numpy(), fx[f"w_{s}_{i}"], REL_TOL, f"w{i} step {s}")
+            assert_close(blk[0].bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], REL_TOL, f"b{i} step {s}")
+        for l in range(c["n_levels"]):
+            lo, hi = net.encoder._row_span(l)
+            assert_close(net.encoder.table.data[lo:hi].cpu().numpy()[fx[f"grad_idx_{l}"]],
+                         fx[f"table_{s}_{l}"], REL_TOL, f"table {l} step {s}")
+
+
+# ------------------------------------------------------------------------ gradient accumulation
+@pytest.mark.parametrize("kind", ["hash_tiny", "siren"])
+def test_gradient_accumulation_equals_one_step_on_the_union(amd, kind):
+    """accumulate_grad_batches = 2 (reference launcher.py:39,159-161): two half batches, each
+    scaled by 1/2, give the gradient -- and the Adam step -- of the concatenated batch."""
+    torch.manual_seed(3)
+    if kind == "hash_tiny":
+        net = amd.models.HashMLP(3, 8, 2, 14, 8, 64, dim_hidden=64, n_layers=3,
+                                 activation=torch.nn.ReLU, batch_norm=False,
+                                 final_activation=False, lr=5e-3)
+        with torch.no_grad():
+            net.encoder.table.uniform_(-0.5, 0.5)
+        lo = 0.0
+    else:
+        net, lo = amd.models.SirenNet(3, 64, 1, 3, lr=1e-4), -1.0
+    nets = [net.cuda(), copy.deepcopy(net).cuda()]
+    steps = [amd.trainer.FusedStep(m, m.configure_optimizers()) for m in nets]
+    n = 6000
+    x = torch.rand(2 * n, 3, device="cuda") * (1 - lo) + lo
+    y = torch.rand(2 * n, 1, device="cuda")
+    for _ in range(2):
+        steps[0].train_step(x, y)
+        l1 = float(steps[1].train_step(x[:n], y[:n], first=True, step=False, divisor=2.0))
+        count = steps[1].opt.step_count
+        l2 = float(steps[1].train_step(x[n:], y[n:], first=False, step=True, divisor=2.0))
+        assert steps[1].opt.step_count == count + 1
+        assert abs(0.5 * (l1 + l2) - float(steps[0].loss)) <= 1e-5 * float(steps[0].loss)
+        assert_close(steps[1].flat.grad.cpu().numpy(), steps[0].flat.grad.cpu().numpy(), REL_TOL,
+                     "accumulated gradient")
+    assert_close(steps[1].flat.param.cpu().numpy(), steps[0].flat.param.cpu().numpy(), 1e-4,
+                 "parameters after two accumulated steps")
+
+
+def test_trainer_accumulates(amd):
+    """Trainer(accumulate_grad_batches=k): one optimiser step per k batches, the epoch's last
+    batch always steps (Lightning's rule)."""
+    from mri_interpolation_amd import config as cfg
+    vol = amd.datamodules.phantom_volume((20, 16, 16)).cpu().numpy()
+    c = cfg.HashConfig().resolve(vol.shape)
+    c.batch_size = 1024                                   # 5 batches per epoch
+    dm = amd.datamodules.MriDataModule(config=c, volume=vol)
+    dm.prepare_data()
+    torch.manual_seed(0)
+    net = amd.models.HashMLP(3, 4, 2, 12, 4, 32, dim_hidden=64, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
+                             lr=5e-3)
+    tr = amd.trainer.Trainer(max_epochs=3, accumulate_grad_batches={0: 2, 2: 5}, log_every=1)
+    tr.fit(net, dm.train_dataloader())
+    assert tr.fused is not None and net.optimizer.step_count == tr.global_step == 3 + 3 + 1
+    assert tr.history[-1] < tr.history[0]
+
+
+# ----------------------------------------------------------- data-parallel step, real RCCL group
+def test_data_parallel_step_through_one_rank_rccl(amd):
+    """The data-parallel FusedStep (gradients pre-divided by the world size, 4 level groups whose
+    all-reduces start asynchronously on RCCL's stream, Adam per group behind its reduction;
+    then the reduce-scatter / sharded-Adam / all-gather form) against a real ONE-rank RCCL
+    communicator, where a sum over ranks is the identity: parameters must equal, bit for bit,
+    those of the same steps without a process group.  (RCCL refuses two ranks on one device; the
+    two-rank runs use gloo: tests/test_00_dp_two_rank_gpu.py.)"""
+    import torch.distributed as dist
+    from mri_interpolation_amd import parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1337)
+        net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3,
+                                 activation=torch.nn.ReLU, batch_norm=False,
+                                 final_activation=False, lr=5e-3)
+        with torch.no_grad():
+            net.encoder.table.uniform_(-0.5, 0.5)
+        nets = [copy.deepcopy(net).cuda() for _ in range(3)]
+        steps = [amd.trainer.FusedStep(m, m.configure_optimizers(), 1) for m in nets]
+        for st in steps:
+            st.world = 2                    # the data-parallel code path: loss pre-divided by 2
+        steps[0].grad_buckets, steps[1].grad_buckets = 4, 4
+        steps[2].grad_buckets, steps[2].dp_mode = 1, "reduce_scatter"
+        calls = dict(ar=0, rs=0, ag=0)
+        real = (parallel.all_reduce_async, parallel.reduce_scatter_sum, parallel.all_gather_shards)
+
+        def ar(flat):
+            calls["ar"] += 1
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+        def rs(flat, rank, world):          # one rank owns the whole (padded) buffer
+            calls["rs"] += 1
+            dist.reduce_scatter_tensor(flat, flat.clone(), op=dist.ReduceOp.SUM)
+            return flat
+
+        def ag(flat, rank, world):
+            calls["ag"] += 1
+            dist.all_gather_into_tensor(flat, flat.clone())
+            return flat
+        g = torch.Generator().manual_seed(5)
+        for _ in range(4):
+            x, y = torch.rand(20001, 3, generator=g).cuda(), torch.rand(20001, 1, generator=g).cuda()
+            parallel.all_reduce_async = ar
+            steps[0].train_step(x, y)
+            parallel.all_reduce_async = real[0]          # no group of > 1 ranks: returns None
+            steps[1].train_step(x, y)
+            parallel.reduce_scatter_sum, parallel.all_gather_shards = rs, ag
+            steps[2].rank, steps[2].world = 0, 2
+            # with ONE rank the shard is the whole buffer: patch shard_range accordingly
+            shard_range = parallel.shard_range
+            parallel.shard_range = lambda numel, rank, world: (0, numel)
+            steps[2].train_step(x, y)
+            parallel.shard_range = shard_range
+            parallel.reduce_scatter_sum, parallel.all_gather_shards = real[1], real[2]
+        torch.cuda.synchronize()
+        assert calls == dict(ar=4 * 5, rs=4, ag=4), calls
+        assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+        assert torch.equal(steps[2].flat.param, steps[1].flat.param)
+        assert torch.equal(steps[2].flat.exp_avg_sq, steps[1].flat.exp_avg_sq)
+    finally:
+        parallel.all_reduce_async, parallel.reduce_scatter_sum, parallel.all_gather_shards = real
+        dist.destroy_process_group()

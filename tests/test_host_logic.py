@@ -179,3 +179,70 @@ def test_resolution_beyond_int64_raises_like_the_reference():
         enc(torch.rand(4, 2))
     assert not encoding.MultiResHashGrid(2, 4, 2, 8, 2, 245)._too_fine
     assert not encoding.MultiResHashGridV2(2, 12, 2, 8, (2, 2), (245, 245))._too_fine
+
+
+# ----------------------------------------------------------------- data-parallel loaders (host)
+class _FakeDataset:
+    """Shape-only stand-in: the loader arithmetic under test never touches the GPU."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.dim_in = len(shape)
+        self.device = "cpu"
+
+    def __len__(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+@pytest.mark.parametrize("shape,world,batch", [((100, 100, 100), 8, 10000),
+                                               ((150, 256, 256), 8, 65536),
+                                               ((6, 40, 40), 8, 500),      # flat-range fallback
+                                               ((352, 352, 6, 8), 8, 1 << 18)])
+def test_sharded_loaders_run_equal_steps(shape, world, batch):
+    """Slabs differ in size whenever the slow axis does not divide by the world size (the
+    first two cases gave 13 vs 12 and 19 vs 18 batches per epoch before): every rank must still
+    run the same number of equal-sized steps, or some ranks leave the all-reduce early."""
+    from mri_interpolation_amd import datamodules, parallel
+    ds = _FakeDataset(shape)
+    loaders = [datamodules.sharded_loader(ds, batch, r, world) for r in range(world)]
+    steps = {len(l) for l in loaders}
+    assert len(steps) == 1
+    n_steps = steps.pop()
+    spans = [parallel.voxel_range(shape, r, world) for r in range(world)]
+    assert n_steps == -(-max(hi - lo for lo, hi in spans) // batch)
+    for l in loaders:
+        assert [l.span(b)[1] for b in range(n_steps)] == [batch] * n_steps
+        assert l.seed != loaders[(loaders.index(l) + 1) % world].seed
+    # slabs tile the volume
+    assert spans[0][0] == 0 and spans[-1][1] == len(ds)
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # one process keeps the reference's loader: last batch of an epoch may be short
+    single = datamodules.sharded_loader(ds, batch, 0, 1)
+    assert single.steps is None and len(single) == -(-len(ds) // batch)
+
+
+def test_accumulate_schedule():
+    from mri_interpolation_amd import trainer
+    assert trainer._accumulate_schedule(None) == {0: 1}
+    assert trainer._accumulate_schedule(4) == {0: 4}
+    sched = trainer._accumulate_schedule({200: 2, 5: 3})   # reference config/base.py:27 form
+    assert list(sched.items()) == [(0, 1), (5, 3), (200, 2)]
+    assert [trainer._accumulate_at(sched, e) for e in (0, 4, 5, 199, 200, 999)] == [1, 1, 3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        trainer._accumulate_schedule(0)
+    with pytest.raises(TypeError):
+        trainer._accumulate_schedule("often")
+
+
+def test_trainer_rejects_unknown_arguments_and_missing_group(monkeypatch):
+    from mri_interpolation_amd import trainer
+    with pytest.raises(TypeError):
+        trainer.Trainer(gradient_clip_val=0.5)   # silently swallowed before
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(RuntimeError, match="no process group"):
+        trainer.Trainer()                        # would pre-divide gradients by 4 and never reduce
+    assert trainer.Trainer(distributed=False).world == 1

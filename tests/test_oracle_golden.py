@@ -11,7 +11,7 @@ from oracle import mlp as omlp
 from oracle import train as otrain
 
 ENC_FIXTURES = ["enc_cfg2", "enc_cfg4", "enc_cfg5_4d", "enc_defaults_2d", "enc_f4_small",
-                "enc_v2_hashconfig", "enc_v2_notebook"]
+                "enc_v2_hashconfig", "enc_v2_notebook", "enc_v2_cfg5"]
 
 
 def _ctor_args(ctor):
@@ -217,6 +217,71 @@ def test_hashmlp_as_intended(mode):
     z = ohash.encode(torch.from_numpy(fx["x"]), tables, res)
     pred = omlp.hashmlp_decoder_forward(z, params, bn, training=(mode == "train"))
     assert_close(pred.numpy(), fx[f"pred_{mode}"], 1e-6, mode)
+
+
+def test_hashmlp_gelu_notebook_decoder():
+    """Notebook cell-37 HashMLP: encoder + Linear -> GELU blocks (no BatchNorm), forward, loss,
+    every gradient and two Adam steps, against the reference modules' outputs."""
+    fx = load_golden("hashmlp_gelu_notebook")
+    m, c = fx.meta, fx.meta["ctor"]
+    res, sizes = ohash.resolutions_for(c["dim"], c["n_levels"], c["log2_hashmap_size"],
+                                       tuple(c["base_resolution"]), tuple(c["finest_resolution"]))
+    assert sizes == m["sizes"]
+    tables = ohash.init_tables(sizes, c["n_features_per_level"], m["table_seed"], m["table_scale"])
+    params = omlp.linear_init(m["dims"], m["mlp_seed"])
+    flat = list(tables) + [t for wb in params for t in wb]
+    opt = omlp.Adam(flat, lr=m["lr"])
+    for step in range(m["steps"]):
+        for p in flat:
+            p.requires_grad_(True)
+            p.grad = None
+        z = ohash.encode(torch.from_numpy(fx[f"x_{step}"]), tables, res)
+        pred = omlp.gelu_mlp_forward(z, params, final_activation=True)
+        loss = omlp.mse_loss(pred, torch.from_numpy(fx[f"y_{step}"]))
+        loss.backward()
+        assert_close(pred.detach().numpy(), fx[f"pred_{step}"], 1e-6, f"pred step {step}")
+        assert abs(float(loss.detach()) - float(fx[f"loss_{step}"])) <= 1e-6 * float(fx[f"loss_{step}"])
+        if step == 0:
+            for l, t in enumerate(tables):
+                nz = torch.nonzero(t.grad.abs().sum(dim=1) != 0).flatten().numpy()
+                np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
+                assert_close(t.grad[nz].numpy(), fx[f"grad_val_{l}"], 1e-6, f"table grad {l}")
+            for i, (w, b) in enumerate(params):
+                assert_close(w.grad.numpy(), fx[f"gw_{i}"], 1e-6, f"gw{i}")
+                assert_close(b.grad.numpy(), fx[f"gb_{i}"], 1e-6, f"gb{i}")
+        grads = [p.grad for p in flat]
+        for p in flat:
+            p.requires_grad_(False)
+        opt.step(grads)
+        for i, (w, b) in enumerate(params):
+            assert_close(w.numpy(), fx[f"w_{step}_{i}"], 1e-6, f"w{i} step {step}")
+            assert_close(b.numpy(), fx[f"b_{step}_{i}"], 1e-6, f"b{i} step {step}")
+        for l, t in enumerate(tables):
+            assert_close(t.numpy()[fx[f"grad_idx_{l}"]], fx[f"table_{step}_{l}"], 1e-6,
+                         f"table {l} step {step}")
+
+
+def test_sample_volume_dataset_4d():
+    """BASELINE config 5's workload: the whole sample volume through the oracle's MriImage
+    restatement (datamodules.py:135-166) -- shape, normalisation, grid order, and agreement
+    with the one slice fixture of round 1."""
+    fx = load_golden("sample_volume")
+    assert fx.meta["shape"] == [352, 352, 6, 15] and fx["raw_int16"].dtype == np.int16
+    vol = (fx["raw_int16"].astype(np.float64) * fx.meta["scl_slope"]
+           + fx.meta["scl_inter"]).astype(np.float32)
+    sl = load_golden("sample_slice_z3_t7")
+    np.testing.assert_array_equal(fx["raw_int16"][:, :, 3, 7], sl["raw_int16"])
+    assert int(fx["raw_int16"].min()) == 0 and int(fx["raw_int16"].max()) == 91  # SURVEY.md section 2
+    coords, pix = odata.dataset(vol)
+    assert coords.shape == (11151360, 4) and pix.shape == (11151360, 1)
+    assert float(pix.min()) == 0.0 and float(pix.max()) == 1.0
+    t = torch.linspace(0, 1, 15)
+    assert torch.equal(coords[:15, 3], t)                       # last axis fastest
+    assert torch.equal(coords[:15 * 6:15, 2], torch.linspace(0, 1, 6))
+    assert torch.equal(coords[::352 * 6 * 15, 0], torch.linspace(0, 1, 352))
+    # held-out-frame protocol (interp.py:27,35): even frames of the FULL time grid
+    even = coords.view(352, 352, 6, 15, 4)[..., ::2, :]
+    assert even.shape[3] == 8 and torch.equal(even[0, 0, 0, :, 3], t[::2])
 
 
 def test_data_grid_and_normalisation():

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""One rank of a data-parallel `Trainer.fit` / `launcher.main` check (started by
+tests/test_00_dp_two_rank_gpu.py, or by torchrun on a multi-GPU node).
+
+    MRI_DIST_BACKEND=gloo MRI_SINGLE_DEVICE=1 python -m torch.distributed.run --nnodes=1 \\
+        --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 tools/dp_fit_check.py OUT
+
+The volume's slow axis (25 slices) does not divide by the world size, so the ranks' slabs differ
+in size: before round 2 the ranks ran 4 and 3 batches per epoch and the run hung in the gradient
+all-reduce.  Checks, per model family (hash + tiny MLP on the bucketed all-reduce path and on the
+reduce-scatter path, SIREN on the flat all-reduce path, the BatchNorm decoder on the autograd
+path): every rank runs the same number of steps, and the replicas hold bitwise identical
+parameters after `fit`.  Rank 0 writes OUT/dp_fit.json.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+from mri_interpolation_amd import config as cfg, datamodules, models, parallel
+from mri_interpolation_amd.trainer import Trainer
+
+
+def build(kind):
+    torch.manual_seed(1337)
+    if kind.startswith("hash"):
+        return models.HashMLP(3, 8, 2, 14, 8, 64, dim_hidden=64, n_layers=3,
+                              activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
+                              lr=5e-3)
+    if kind == "siren":
+        return models.SirenNet(dim_in=3, dim_hidden=64, dim_out=1, n_layers=3, lr=1e-4)
+    return models.HashMLP(3, 4, 2, 12, (8, 8, 8), (32, 32, 32), dim_hidden=32, n_layers=2,
+                          lr=5e-3)  # the reference's BatchNorm + GELU decoder: autograd path
+
+
+def main():
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else "."
+    rank, world, local = parallel.init()
+    assert world > 1, "launch with 2 or more ranks"
+    torch.cuda.set_device(local)
+    vol = datamodules.phantom_volume((25, 32, 32)).cpu().numpy()
+    report = {}
+    for kind in ("hash", "hash_rs", "siren", "batchnorm"):
+        c = (cfg.HashConfig() if kind != "siren" else cfg.BaseConfig()).resolve(vol.shape)
+        c.batch_size = 4096
+        dm = datamodules.MriDataModule(config=c, volume=vol, norm_siren=kind == "siren")
+        dm.prepare_data()
+        loader = dm.train_dataloader(rank, world)
+        net = build(kind).cuda()
+        tr = Trainer(max_epochs=2, accumulate_grad_batches=2 if kind == "hash" else None,
+                     dp_mode="reduce_scatter" if kind == "hash_rs" else "all_reduce")
+        tr.fit(net, loader)
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        mine = flat.cpu() if dist.get_backend() == "gloo" else flat
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        same = all(torch.equal(gathered[0], t) for t in gathered)
+        steps = torch.tensor([float(tr.global_step)])
+        if dist.get_backend() != "gloo":
+            steps = steps.cuda()
+        hi, lo = steps.clone(), steps.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        report[kind] = dict(batches_per_epoch=len(loader), optimizer_steps=tr.global_step,
+                            steps_min=int(lo), steps_max=int(hi), replicas_identical=bool(same),
+                            fused=tr.fused is not None, finite=bool(torch.isfinite(flat).all()),
+                            moved=bool((flat != torch.cat([p.detach().reshape(-1) for p in
+                                                           build(kind).cuda().parameters()])).any()))
+        assert same, f"{kind}: replicas differ after fit"
+        assert int(lo) == int(hi), f"{kind}: ranks ran {int(lo)}..{int(hi)} steps"
+    parallel.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "dp_fit.json"), "w") as f:
+            json.dump(report, f)
+        print("dp fit check ok", json.dumps(report))
+
+
+if __name__ == "__main__":
+    main()
