@@ -428,6 +428,65 @@ def tiny_mlp_train_slice(x_fm, target, col_offset: int, n: int, params, grads, l
     return loss_out
 
 
+# --------------------------------------------------------------------------- fused SIREN chain
+def siren_supported(dim_in: int, hidden: int, n_sine_layers: int, dim_out: int) -> bool:
+    return bool(_lib.load().mri_siren_supported(dim_in, hidden, n_sine_layers, dim_out))
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def siren_forward(x, weights, biases, w0_first: float, w0: float, act=None, deriv=None, y=None):
+    """y (n, 1) = SirenNet(x) in one persistent kernel (csrc/siren_chain.hip).  weights / biases:
+    the sine layers' then the head's; act / deriv: per sine layer (n, hidden) buffers that receive
+    sin(.) and w0 cos(.) for the backward pass (both None: inference, nothing but y is written)."""
+    _gpu(x, y, *weights, *biases, *(act or []), *(deriv or []))
+    x = _rowmajor(x).contiguous()
+    n, dim_in = x.shape
+    n_sine, hidden = len(weights) - 1, weights[0].shape[0]
+    if y is None:
+        y = torch.empty((n, 1), device=x.device, dtype=torch.float32)
+    for t in list(weights) + list(biases) + list(act or []) + list(deriv or []):
+        if not t.is_contiguous():
+            raise ValueError("siren_forward needs contiguous parameters and buffers")
+    if (act is None) != (deriv is None) or (act is not None and
+                                            (len(act) != n_sine or len(deriv) != n_sine)):
+        raise ValueError("act and deriv: one (n, hidden) buffer per sine layer, or both None")
+    _lib.call("mri_siren_forward", _ptr(x), n, dim_in, hidden, n_sine, _ptr_array(weights),
+              _ptr_array(biases), float(w0_first), float(w0),
+              _ptr_array(act) if act is not None else None,
+              _ptr_array(deriv) if deriv is not None else None, _ptr(y), _stream())
+    return y
+
+
+_siren_workspace = {}
+
+
+def siren_backward(x, dy, weights, act, deriv, dz, d_weights, d_biases):
+    """Gradients of the fused SIREN chain, ADDED to d_weights / d_biases (sine layers, then the
+    head).  dy: (n, 1) loss gradient w.r.t. the prediction; act / deriv: what siren_forward
+    stored; dz: per sine layer (n, hidden) scratch (dz[0] may be None)."""
+    _gpu(x, dy, *weights, *act, *deriv, *[t for t in dz if t is not None], *d_weights, *d_biases)
+    x = _rowmajor(x).contiguous()
+    n, dim_in = x.shape
+    n_sine, hidden = len(weights) - 1, weights[0].shape[0]
+    if not (len(act) == len(deriv) == len(dz) == n_sine and
+            len(d_weights) == len(d_biases) == n_sine + 1):
+        raise ValueError("siren_backward: one act / deriv / dz per sine layer, one gradient per layer")
+    need = _lib.load().mri_siren_backward_workspace_bytes(n, n_sine)
+    ws = _siren_workspace.get(x.device.index)
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            torch.cuda.synchronize(x.device)
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        _siren_workspace[x.device.index] = ws
+    dz_ptrs = (C.c_void_p * n_sine)(*[t.data_ptr() if t is not None else None for t in dz])
+    _lib.call("mri_siren_backward", _ptr(x), _ptr(dy), n, dim_in, hidden, n_sine,
+              _ptr_array(weights), _ptr_array(act), _ptr_array(deriv), dz_ptrs,
+              _ptr_array(d_weights), _ptr_array(d_biases), _ptr(ws), ws.numel() * 4, _stream())
+
+
 # --------------------------------------------------------------------------- loss / optimiser
 def mse_loss(pred, target, loss_out, d_pred=None, grad_divisor: float = 1.0):
     """loss_out[0] += mean((pred - target)^2); d_pred = 2 (pred - target) / (N * divisor)."""

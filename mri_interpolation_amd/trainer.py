@@ -85,6 +85,8 @@ class FusedStep:
         self._table_grad = self.flat.grad_view(self.encoder.table) if self.encoder else None
         self.tiny = self._tiny_mlp_plan()
         self.use_tiny = self.tiny is not None
+        self.chain = self._siren_chain_plan()
+        self.use_chain = self.chain is not None
         # Data parallel: the table gradient is produced level by level, so its reduction is cut
         # into `grad_buckets` level groups; group g's all-reduce (RCCL, its own stream) runs
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
@@ -127,6 +129,23 @@ class FusedStep:
         if not ops.tiny_mlp_supported(k_in, h, 1):
             return None
         return dict(params=[(l.weight.data, l.bias.data) for l in ls], grads=self._grads)
+
+    def _siren_chain_plan(self):
+        """Arguments of the fused SIREN chain kernels (csrc/siren_chain.hip) if the model is
+        dim_in -> 256 x n (sine) -> 1 (linear head) with biases everywhere."""
+        ls = self.layers
+        if self.encoder is not None or len(ls) < 2 or any(l.bias is None for l in ls):
+            return None
+        if any(l.activation != ops.ACT_SINE for l in ls[:-1]) or ls[-1].activation != ops.ACT_IDENTITY:
+            return None
+        hidden, dim_in = ls[0].weight.shape
+        if any(l.weight.shape != (hidden, hidden) for l in ls[1:-1]) or ls[-1].weight.shape != (1, hidden):
+            return None
+        if len({l.w0 for l in ls[1:-1]}) > 1 or not ops.siren_supported(dim_in, hidden, len(ls) - 1, 1):
+            return None
+        return dict(weights=[l.weight.data for l in ls], biases=[l.bias.data for l in ls],
+                    w0_first=ls[0].w0, w0=ls[1].w0 if len(ls) > 2 else ls[0].w0,
+                    d_weights=[g[0] for g in self._grads], d_biases=[g[1] for g in self._grads])
 
     @contextlib.contextmanager
     def _phase(self, name: str):
@@ -187,6 +206,13 @@ class FusedStep:
                 return ops.tiny_mlp_forward(x, self.tiny["params"], y=ws["y"][-1]), ws
         if self.use_tiny:
             return x, ws  # the training kernel runs forward and backward together
+        if self.use_chain:  # every layer of a row tile in one kernel, activations stay in LDS
+            c, n_sine = self.chain, len(self.layers) - 1
+            with self._phase("mlp_fwd"):
+                ops.siren_forward(x, c["weights"], c["biases"], c["w0_first"], c["w0"],
+                                  act=ws["y"][:n_sine] if train else None,
+                                  deriv=ws["deriv"][:n_sine] if train else None, y=ws["y"][-1])
+            return ws["y"][-1], ws
         with self._phase("mlp_fwd"):
             for i, l in enumerate(self.layers):
                 deriv = ws["deriv"][i] if train else None
@@ -331,6 +357,12 @@ class FusedStep:
             ops.mse_loss(pred, target, self.loss, dz, grad_divisor=div)
             mode, g = self._deriv_of(last, ws)
             ops.apply_deriv(dz, mode, g)
+        if self.use_chain:
+            c, n_sine = self.chain, last
+            with self._phase("mlp_bwd"):
+                ops.siren_backward(coords, dz, c["weights"], ws["y"][:n_sine], ws["deriv"][:n_sine],
+                                   [None] + ws["dz"][1:n_sine], c["d_weights"], c["d_biases"])
+            return
         with self._phase("mlp_bwd"):
             for i in range(last, -1, -1):
                 l = self.layers[i]

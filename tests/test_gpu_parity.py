@@ -19,7 +19,8 @@ from oracle import train as otrain
 pytestmark = pytest.mark.gpu
 
 ENC_FIXTURES = ["enc_cfg2", "enc_cfg4", "enc_cfg5_4d", "enc_defaults_2d", "enc_f4_small",
-                "enc_v2_hashconfig", "enc_v2_notebook"]
+                "enc_v2_hashconfig", "enc_v2_notebook",
+                "enc_v2_cfg5"]  # the per-axis 4-D encoder BASELINE config 5 trains with
 
 
 @pytest.fixture(scope="module")

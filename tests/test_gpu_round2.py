@@ -82,30 +82,29 @@ def test_sample_volume_through_nifti_and_mriimage_4d(amd, sample_volume):
     assert int(seen.min()) == 1 and int(seen.max()) == 1
 
 
-def test_config5_encoder_golden(amd):
-    """The encoder config 5 trains with (per-axis MultiResHashGridV2, 4-D: 16 corners) against the
-    reference's outputs and table gradients, all three backward methods."""
+def check_table_gradient(g_l, idx, val, what):
+    """One level's table gradient against the reference's sparse (rows, values): hashing is
+    integer work -- nothing may land outside the reference's slots, no slot of any weight may be
+    lost (contributions below ~2^-40 max|g| may round to zero in the fixed-point sum)."""
+    want = np.zeros_like(g_l)
+    want[idx] = val
+    nz = np.nonzero(np.abs(g_l).sum(axis=1))[0]
+    assert np.isin(nz, idx).all(), f"{what}: stray slot"
+    big = np.abs(want).sum(axis=1) > 1e-9 * np.abs(want).max()
+    assert (np.abs(g_l).sum(axis=1)[big] != 0).all(), f"{what}: lost slot"
+    assert_close(g_l, want, REL_TOL, what)
+
+
+def test_config5_encoder_is_the_pinned_one(amd):
+    """bench.py's / the launcher test's config-5 encoder IS the one pinned by the golden
+    `enc_v2_cfg5` (forward + three backward methods: test_gpu_parity.py's fixture sweep)."""
+    import bench
     fx = load_golden("enc_v2_cfg5")
-    enc = amd.encoding.MultiResHashGridV2(4, n_levels=16, n_features_per_level=2,
-                                          log2_hashmap_size=19, base_resolution=CFG5_BASE,
-                                          finest_resolution=CFG5_FINEST)
-    assert enc.sizes == fx.meta["sizes"]
-    tabs = ohash.init_tables(enc.sizes, 2, fx.meta["table_seed"], fx.meta["table_scale"])
-    with torch.no_grad():
-        enc.table.copy_(torch.cat(tabs))
-    enc = enc.cuda()
-    x = cuda(fx["x"])
-    with torch.no_grad():
-        assert_close(enc(x).cpu().numpy(), fx["out"], 1e-6, "forward")
-    for method in (0, 1, 2):
-        g = torch.zeros_like(enc.table.data)
-        amd.ops.hashgrid_backward(enc.desc, x, cuda(fx["d_out"]), g, method=method)
-        g = g.cpu().numpy()
-        for l in range(16):
-            lo, hi = enc._row_span(l)
-            nz = np.nonzero(np.abs(g[lo:hi]).sum(1))[0]
-            np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
-            assert_close(g[lo:hi][nz], fx[f"grad_val_{l}"], REL_TOL, f"method {method} level {l}")
+    w = bench.WORKLOADS["cfg5"]
+    assert list(w["base"]) == fx.meta["ctor"]["base_resolution"] == list(CFG5_BASE)
+    assert list(w["finest"]) == fx.meta["ctor"]["finest_resolution"] == list(CFG5_FINEST)
+    enc = bench.build_model(w).encoder
+    assert enc.sizes == fx.meta["sizes"] and enc.dim == 4 and enc.n_levels == 16
 
 
 def test_config5_protocol_on_the_sample_volume(amd, sample_volume, tmp_path):
@@ -249,9 +248,8 @@ def test_hashmlp_gelu_notebook_decoder(amd, path):
             g = net.encoder.table.grad.cpu().numpy()
             for l in range(c["n_levels"]):
                 lo, hi = net.encoder._row_span(l)
-                nz = np.nonzero(np.abs(g[lo:hi]).sum(1))[0]
-                np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
-                assert_close(g[lo:hi][nz], fx[f"grad_val_{l}"], REL_TOL, f"table grad {l}")
+                check_table_gradient(g[lo:hi], fx[f"grad_idx_{l}"], fx[f"grad_val_{l}"],
+                                     f"table grad {l}")
             for i, blk in enumerate(net.decoder):
                 assert_close(blk[0].weight.grad.cpu().numpy(), fx[f"gw_{i}"], REL_TOL, f"gw{i}")
                 assert_close(blk[0].bias.grad.cpu().numpy(), fx[f"gb_{i}"], REL_TOL, f"gb{i}")
