@@ -251,6 +251,39 @@ def round2_fixtures(encoding, models):
               sizes=sizes, resolutions=res, table_seed=91, table_scale=0.5, mlp_seed=92,
               dims=[16, 64, 1], lr=5e-3, steps=2), **arrays)
 
+    # ---- O6c: end-to-end SIREN at the width of BASELINE config 3 (3 -> 256 x 5 -> 1), 3 Adam steps:
+    #      the shape the fused chain kernels (csrc/siren_chain.hip) serve ---------------------------
+    net = models.SirenNet(dim_in=3, dim_hidden=256, dim_out=1, n_layers=5)
+    params = omlp.siren_init(3, 256, 1, 5, 63)
+    layers = list(net.layers) + [net.last_layer]
+    with torch.no_grad():
+        for layer, (w, b) in zip(layers, params):
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+    opt = net.configure_optimizers()
+    arrays = {}
+    for step in range(3):
+        x = detrand.uniform(600 * 3, 760 + step, -1.0, 1.0).reshape(600, 3)
+        y = detrand.uniform(600, 770 + step, -1.0, 1.0).reshape(600, 1)
+        opt.zero_grad()
+        loss = net.training_step((torch.from_numpy(x), torch.from_numpy(y)), step)
+        loss.backward()
+        if step == 0:
+            arrays["pred_0"] = net(torch.from_numpy(x)).detach().numpy().copy()
+            for i, layer in enumerate(layers):
+                arrays[f"gb_{i}"] = layer.bias.grad.numpy().copy()
+                arrays[f"gw_head_{i}"] = layer.weight.grad.numpy()[:8].copy()
+        opt.step()
+        arrays[f"x_{step}"], arrays[f"y_{step}"] = x, y
+        arrays[f"loss_{step}"] = np.float32(loss.item())
+        for i, layer in enumerate(layers):
+            w = layer.weight.detach().numpy()
+            arrays[f"w_{step}_{i}"] = (w if w.size <= 8192 else w[:16]).copy()  # head rows suffice
+            arrays[f"wnorm_{step}_{i}"] = np.float64(np.linalg.norm(w.astype(np.float64)))
+            arrays[f"b_{step}_{i}"] = layer.bias.detach().numpy().copy()
+    save("e2e_siren256_adam", dict(dim_in=3, dim_hidden=256, n_layers=5, seed=63, lr=1e-4, steps=3),
+         **arrays)
+
     # ---- O8b: the sample volume itself ----------------------------------------------------------
     vol, shape, slope, inter = read_sample_volume()
     save("sample_volume", dict(shape=list(shape), scl_slope=slope, scl_inter=inter,

@@ -202,6 +202,118 @@ def test_full_size_cfg3_siren_intensities_and_step(amd):
         assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), 5e-5, f"gb{i}")
 
 
+# --------------------------------------------------------------------- fused SIREN chain kernels
+def _load_siren(amd, m):
+    net = amd.models.SirenNet(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], lr=m.get("lr", 1e-4))
+    with torch.no_grad():
+        for layer, (w, b) in zip(list(net.layers) + [net.last_layer],
+                                 omlp.siren_init(m["dim_in"], m["dim_hidden"], 1, m["n_layers"],
+                                                 m["seed"])):
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+    return net.cuda()
+
+
+def test_siren_chain_e2e_adam_golden(amd):
+    """Three Adam steps of SirenNet(3 -> 256 x 5 -> 1) through the fused chain kernels
+    (csrc/siren_chain.hip: forward, backward-data and weight-gradient passes) against the
+    reference's torch.optim.Adam on the reference modules."""
+    fx = load_golden("e2e_siren256_adam")
+    m = fx.meta
+    net = _load_siren(amd, m)
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    assert step.use_chain
+    layers = list(net.layers) + [net.last_layer]
+    with torch.no_grad():
+        assert_close(step.forward(cuda(fx["x_0"]), train=False)[0].cpu().numpy(), fx["pred_0"],
+                     REL_TOL, "inference kernel")
+    for s in range(m["steps"]):
+        x, y = cuda(fx[f"x_{s}"]), cuda(fx[f"y_{s}"])
+        if s == 0:  # gradients of the first step
+            pred, ws = step.forward(x, train=True)
+            assert_close(pred.cpu().numpy(), fx["pred_0"], REL_TOL, "training kernel")
+            step.backward(x, y, ws)
+            for i, layer in enumerate(layers):
+                assert_close(layer.bias.grad.cpu().numpy(), fx[f"gb_{i}"], REL_TOL, f"gb{i}")
+                head = fx[f"gw_head_{i}"]
+                assert_close(layer.weight.grad.cpu().numpy()[:head.shape[0]], head, REL_TOL, f"gw{i}")
+        loss = float(step.train_step(x, y))
+        assert abs(loss - float(fx[f"loss_{s}"])) <= REL_TOL * abs(float(fx[f"loss_{s}"]))
+        for i, layer in enumerate(layers):
+            # Gradients (above) agree to 1e-5.  Adam's first steps are lr g / (|g| + eps): an
+            # element whose gradient is ~eps = 1e-8 turns a 1e-9 difference of g into 0.1 lr =
+            # 1e-5 of weight, i.e. 6e-5 of max |w| = 0.15 -- for either of two correct f32
+            # evaluations.  As in test_full_size_cfg4_step_matches_oracle: 1e-4 after Adam, and
+            # the norm (which such isolated elements do not move) at 1e-5.
+            w = layer.weight.detach().cpu().numpy()
+            head = fx[f"w_{s}_{i}"]
+            assert_close(w[:head.shape[0]], head, 1e-4, f"w{i} step {s}")
+            assert abs(np.linalg.norm(w.astype(np.float64)) - float(fx[f"wnorm_{s}_{i}"])) \
+                <= REL_TOL * float(fx[f"wnorm_{s}_{i}"])
+            assert_close(layer.bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], 1e-4, f"b{i} step {s}")
+
+
+@pytest.mark.parametrize("dim_in,n_layers", [(3, 5), (2, 2), (4, 1), (1, 8)])
+@pytest.mark.parametrize("n", [1, 63, 65, 1000, 33000])
+def test_siren_chain_matches_oracle_and_layerwise(amd, dim_in, n_layers, n):
+    """Ragged batches (tiles of 64 rows, chunks of 32), 1 .. 8 sine layers, 1-4 input
+    coordinates: predictions, loss and every gradient of the chain kernels against the oracle,
+    and against the layer-wise GEMM path of the same library (use_chain = False)."""
+    m = dict(dim_in=dim_in, dim_hidden=256, n_layers=n_layers, seed=100 + n_layers)
+    net = _load_siren(amd, m)
+    model = otrain.SirenModel(dim_in, 256, 1, n_layers, seed=m["seed"])
+    x = torch.from_numpy(detrand.uniform(n * dim_in, n + 1, -1.0, 1.0).reshape(n, dim_in))
+    y = torch.from_numpy(detrand.uniform(n, n + 2, -1.0, 1.0).reshape(n, 1))
+    want_loss, want_pred, grads = otrain.loss_and_grads(model, x, y)
+    nets = [net, copy.deepcopy(net)]
+    steps = [amd.trainer.FusedStep(q, q.configure_optimizers()) for q in nets]
+    assert steps[0].use_chain
+    steps[1].use_chain = False
+    for st, q in zip(steps, nets):
+        pred, ws = st.forward(x.cuda(), train=True)
+        st.backward(x.cuda(), y.cuda(), ws)
+        # intensities relative to the output range (a batch of ONE row has no range of its own:
+        # its single prediction may be a near-cancellation of the head's 256 terms)
+        err = np.abs(pred.cpu().numpy() - want_pred.numpy()).max()
+        assert err <= REL_TOL * max(float(want_pred.abs().max()), 0.1), err
+        assert abs(float(st.loss) - float(want_loss)) <= REL_TOL * max(abs(float(want_loss)), 0.1)
+        for i, layer in enumerate(list(q.layers) + [q.last_layer]):
+            assert_close(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), REL_TOL, f"gw{i}")
+            assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), REL_TOL, f"gb{i}")
+    # gradients ACCUMULATE (the kernels add): a second backward doubles them
+    g1 = steps[0].flat.grad.clone()
+    pred, ws = steps[0].forward(x.cuda(), train=True)
+    steps[0].backward(x.cuda(), y.cuda(), ws, first=False)
+    assert_close(steps[0].flat.grad.cpu().numpy(), 2 * g1.cpu().numpy(), 1e-6, "accumulated")
+
+
+def test_siren_chain_is_bitwise_reproducible(amd):
+    """No float atomics: slabs summed in a fixed order -> same bits on every run."""
+    net = _load_siren(amd, dict(dim_in=3, dim_hidden=256, n_layers=5, seed=7))
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    x = torch.rand(70001, 3, device="cuda") * 2 - 1
+    y = torch.rand(70001, 1, device="cuda")
+    runs = []
+    for _ in range(3):
+        pred, ws = step.forward(x, train=True)
+        step.backward(x, y, ws)
+        runs.append((pred.clone(), step.flat.grad.clone()))
+        torch.empty(1 << 24, device="cuda").normal_()  # disturb the allocator / caches
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+
+
+def test_siren_chain_rejects_unsupported_shapes(amd):
+    ops = amd.ops
+    assert ops.siren_supported(3, 256, 5, 1) and not ops.siren_supported(3, 128, 5, 1)
+    assert not ops.siren_supported(9, 256, 5, 1) and not ops.siren_supported(3, 256, 9, 1)
+    net = amd.models.SirenNet(3, 64, 1, 3).cuda()           # other widths: layer by layer
+    assert not amd.trainer.FusedStep(net, net.configure_optimizers()).use_chain
+    ws = [torch.zeros(128, 3, device="cuda"), torch.zeros(1, 128, device="cuda")]
+    bs = [torch.zeros(128, device="cuda"), torch.zeros(1, device="cuda")]
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.siren_forward(torch.zeros(4, 3, device="cuda"), ws, bs, 30.0, 30.0)
+
+
 # ----------------------------------------------------------------- notebook Linear -> GELU decoder
 @pytest.mark.parametrize("path", ["module", "fused"])
 def test_hashmlp_gelu_notebook_decoder(amd, path):

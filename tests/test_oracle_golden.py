@@ -196,6 +196,29 @@ def test_e2e_siren_adam():
             assert_close(b.numpy(), fx[f"b_{step}_{i}"], 1e-6, f"b{i} step {step}")
 
 
+def test_e2e_siren256_adam():
+    """SIREN at BASELINE config 3's width (3 -> 256 x 5 -> 1): three Adam steps against the
+    reference; the GPU test runs the same fixture through the fused chain kernels."""
+    fx = load_golden("e2e_siren256_adam")
+    m = fx.meta
+    model = otrain.SirenModel(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], seed=m["seed"])
+    assert_close(model.forward(torch.from_numpy(fx["x_0"])).numpy(), fx["pred_0"], 1e-6, "pred")
+    opt = None
+    for step in range(m["steps"]):
+        batch = [(torch.from_numpy(fx[f"x_{step}"]), torch.from_numpy(fx[f"y_{step}"]))]
+        losses, opt = otrain.train_steps(model, batch, m["lr"], opt)
+        assert abs(losses[0] - float(fx[f"loss_{step}"])) <= 1e-6 * abs(float(fx[f"loss_{step}"]))
+        for i, (w, b) in enumerate(model.params):
+            head = fx[f"w_{step}_{i}"]
+            # Adam's first steps are lr * g / (|g| + eps): where |g| ~ eps a last-bit difference
+            # of the gradient (torch's fused mm backward vs the oracle's) moves the weight by a
+            # fraction of lr = 1e-4, i.e. ~1.5e-6 of max |w| = 0.15 here: 5e-6, not 1e-6
+            assert_close(w.numpy()[:head.shape[0]], head, 5e-6, f"w{i} step {step}")
+            assert abs(np.linalg.norm(w.numpy().astype(np.float64)) - float(fx[f"wnorm_{step}_{i}"])) \
+                <= 1e-6 * float(fx[f"wnorm_{step}_{i}"])
+            assert_close(b.numpy(), fx[f"b_{step}_{i}"], 5e-6, f"b{i} step {step}")
+
+
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_hashmlp_as_intended(mode):
     fx = load_golden("hashmlp_intended")

@@ -1,0 +1,18 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mri_interpolation_amd import _lib, models, ops, trainer
+_lib.load()
+net = models.SirenNet(3, 256, 1, 5).cuda()
+st = trainer.FusedStep(net, net.configure_optimizers())
+n = 1 << 20
+x = torch.rand(n, 3, device="cuda") * 2 - 1
+y = torch.rand(n, 1, device="cuda")
+def timed(fn, reps=8):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+ws = st.forward(x, train=True)[1]
+print(os.environ.get("MRI_LIB", "default"), "infer %.3f  fwd %.3f  bwd %.3f  step %.3f ms" % (
+    timed(lambda: st.forward(x, train=False)), timed(lambda: st.forward(x, train=True)),
+    timed(lambda: st.backward(x, y, ws)), timed(lambda: st.train_step(x, y))))
