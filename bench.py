@@ -236,6 +236,8 @@ def main():
                          "(0 = one slice); default: FusedStep's")
     ap.add_argument("--opt", action="append", default=[],
                     help="library tuning option name=value (mri_set_option), repeatable")
+    ap.add_argument("--overlap-forward", action="store_true",
+                    help="run the hash-grid lookup beside the decoder kernel (FusedStep.overlap_forward)")
     ap.add_argument("--mode", default="train", choices=["train", "predict"],
                     help="predict: inference throughput of the same model on the dense grid of "
                          "the volume (launcher.py's predict / interpolate passes), no training")
@@ -276,6 +278,7 @@ def main():
     step = trainer.FusedStep(model, opt, world)
     step.bwd_method = args.bwd_method
     step.dp_mode = args.dp_mode
+    step.overlap_forward = args.overlap_forward
     if args.grad_buckets:
         step.grad_buckets = args.grad_buckets
     if args.split is not None:

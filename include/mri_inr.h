@@ -224,6 +224,32 @@ int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, 
                              float* loss_out, float* y, int32_t overwrite, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* ---- lookup and decoder running side by side ----------------------------------------------
+ * The decoder kernel is bound by the f32 matrix rate and leaves the texture path idle; the lookup
+ * is bound by the texture path, needs no LDS and 27 registers.  Launched on two streams they share
+ * the CUs: mri_hashgrid_forward_signal (queue it FIRST) produces the feature-major block
+ * (L*2, out_ld) slice by slice -- a slice = slice_rows consecutive coordinates =
+ * mri_tiny_mlp_round_rows(), what one round of the decoder's workgroups reads -- and adds
+ * mri_hashgrid_forward_signal_blocks() to ready[slice] as its blocks finish (write-through stores,
+ * agent-scope counter; the counters only ever grow: the caller keeps the running total and passes
+ * it as ready_target).  mri_tiny_mlp_train_overlapped is mri_tiny_mlp_train[_overwrite] whose
+ * workgroups wait for ready[r] >= ready_target before touching round r's rows (bounded wait: a
+ * producer that never arrives sets *status = 1 instead of hanging the GPU).  Same results as the
+ * two plain calls, bit for bit.  Needs n_features == 2, 2 <= dim <= 4, hidden == 128. */
+int64_t mri_hashgrid_forward_signal_blocks(const mri_grid_desc* grid, int64_t slice_rows);
+int mri_hashgrid_forward_signal(const mri_grid_desc* grid, const float* x, int64_t n,
+                                const float* table, float* out, int64_t out_ld,
+                                int64_t slice_rows, uint64_t* ready, void* stream);
+int64_t mri_tiny_mlp_round_rows(int32_t k_in, int32_t hidden, int64_t n);
+int mri_tiny_mlp_train_overlapped(const float* x, const float* target, int64_t n, int32_t k_in,
+                                  int32_t hidden, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, const float* w3,
+                                  const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                  float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                  float* loss_out, int32_t overwrite, const uint64_t* ready,
+                                  uint64_t ready_target, int32_t* status, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
 /* ---- fused SIREN chain -------------------------------------------------------------------
  * SirenNet.forward (reference models.py:230-233): n_sine_layers x [F.linear -> sin(w0 .)]
  * (SirenLayer.forward, models.py:153-156; the first layer with w0_first) and the linear head,

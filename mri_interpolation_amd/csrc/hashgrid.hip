@@ -167,6 +167,91 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(
   if (live) __builtin_nontemporal_store(total, out + (int64_t)level * sl + i * sr + xc * sf);
 }
 
+// The same lookup for a CONSUMER THAT RUNS BESIDE IT (the fused decoder kernel of mlp_fused.hip,
+// launched on another stream): blocks are ordered slice-major -- a slice = `slice_rows`
+// consecutive coordinates = what one round of the consumer's workgroups reads -- and every block
+// adds 1 to its slice's counter when its features are visible device-wide.  The consumer polls
+// the counter before it touches a slice, so the MFMA-bound decoder starts as soon as the first
+// slices are encoded and the rest of the lookup (address-path bound, no LDS, 30 VGPRs) runs in
+// the issue slots and the register space the decoder leaves free.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): features leave through
+// write-through (sc0 sc1) 16-byte stores -- four neighbouring coordinates of one feature,
+// collected with three lane shuffles -- every storing wave drains its stores (vmcnt(0)), the
+// workgroup meets at a barrier, ONE lane then adds to the counter at agent scope.  The consumer
+// polls relaxed, fences once (agent acquire) and reads with plain loads.
+constexpr int kSignalChunks = 8;
+
+template <int D>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pair_signal_kernel(
+    const LevelTab tab, const Sched sched, int blocks_per_slice, int64_t slice_rows,
+    const float* __restrict__ x, int64_t n, const float* __restrict__ table,
+    float* __restrict__ out, int64_t ld, unsigned long long* __restrict__ ready) {
+  // beside the decoder's MFMA waves (f32 MFMAs run on the vector ALUs) this kernel's ~150 vector
+  // instructions per coordinate and level only issue when they win the arbitration
+  __builtin_amdgcn_s_setprio(3);
+  const int slice = blockIdx.x / blocks_per_slice;
+  const int b = blockIdx.x - slice * blocks_per_slice;
+  int level, chunk;
+  {  // decode() on the block index within the slice
+    const int xcd = b & 7, r = b >> 3;
+    const int q = r / sched.chunks_per_slot, j = r - q * sched.chunks_per_slot;
+    const int slot = xcd + 8 * q;
+    level = slot % sched.n_levels;
+    const int rank = slot / sched.n_levels;
+    const int cnt = (sched.virtual_levels - 1 - level) / sched.n_levels + 1;
+    chunk = j * cnt + rank;
+  }
+  const int64_t row0 = (int64_t)slice * slice_rows;
+  const int64_t rows = min(slice_rows, n - row0);
+  // a block walks kSignalChunks chunks of 128 coordinates: the drain + barrier + counter update
+  // at its end (1-2 us: the write-through stores must be acknowledged) is paid once per
+  // kSignalChunks x 128 coordinates -- with one chunk per block it tripled the kernel's time
+  const uint32_t size = tab.size[level], magic = tab.magic[level];
+  const bool pow2 = tab.pow2[level] != 0;
+  const float* __restrict__ rows_p = table + tab.offset[level] * 2;
+  const int xc = threadIdx.x & 1;
+  const bool aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  for (int sub = 0; sub < kSignalChunks; ++sub) {
+    const int64_t c0 = ((int64_t)chunk * kSignalChunks + sub) * 128;
+    if (chunk >= sched.chunks || c0 >= rows) break;  // block-uniform
+    const int64_t i = row0 + c0 + (threadIdx.x >> 1);
+    const bool live = i < row0 + rows;
+    const Cell<D> c = locate<D>(x, live ? i : n - 1, tab.res[level]);
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < (1 << (D - 1)); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, (nb << 1) | xc, h, w);
+      const float2 v = *reinterpret_cast<const float2*>(
+          rows_p + (uint64_t)slot_of(h, size, magic, pow2) * 2);
+      p0 = p0 + v.x * w;
+      p1 = p1 + v.y * w;
+    }
+    const float mine = xc ? p1 : p0, send = xc ? p0 : p1;
+    const float total = mine + __shfl_xor(send, 1, 64);
+    // feature-major destination: row (2 level + xc) of `out`, column i
+    float* __restrict__ dst = out + ((int64_t)level * 2 + xc) * ld + i;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v quad;
+    quad.x = total;
+    quad.y = __shfl_down(total, 2, 64);
+    quad.z = __shfl_down(total, 4, 64);
+    quad.w = __shfl_down(total, 6, 64);
+    const bool quad_inside = aligned && (i & ~int64_t(3)) + 3 < row0 + rows;
+    if (quad_inside) {
+      if ((i & 3) == 0)  // one lane of four stores the four coordinates' values, 16 bytes
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(quad) : "memory");
+    } else if (live) {
+      asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(total) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(ready + slice, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D, int F>
 __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(
     const LevelTab tab, const Sched sched, const uint32_t level_mask, const float* __restrict__ x,
@@ -243,6 +328,25 @@ struct BwdAtomicLaunch {
   }
 };
 
+// blocks of one slice of the signalling forward kernel: every (virtual level, chunk slot)
+int signal_blocks_per_slice(const Sched& s) { return s.virtual_levels * s.chunks_per_slot; }
+
+template <int D, int F>
+struct FwdSignalLaunch {
+  static int run(const LevelTab& tab, const Sched& sched, int64_t slice_rows, int slices,
+                 const float* x, int64_t n, const float* table, float* out, int64_t ld,
+                 unsigned long long* ready, hipStream_t st) {
+    if constexpr (F == 2 && D >= 2 && D <= 4) {
+      const int per = signal_blocks_per_slice(sched);
+      hipLaunchKernelGGL((hashgrid_fwd_pair_signal_kernel<D>), dim3((unsigned)(per * slices)),
+                         dim3(256), 0, st, tab, sched, per, slice_rows, x, n, table, out, ld, ready);
+      return check_launch("hashgrid_fwd_pair_signal_kernel");
+    } else {
+      return fail(MRI_ERR_UNSUPPORTED, "signalling forward needs 2 features, 2 <= dim <= 4");
+    }
+  }
+};
+
 }  // namespace
 
 int launch_backward_atomic(const mri_grid_desc* grid, uint32_t level_mask, const float* x,
@@ -274,3 +378,30 @@ extern "C" int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, i
                              (hipStream_t)stream);
 }
 
+
+extern "C" int64_t mri_hashgrid_forward_signal_blocks(const mri_grid_desc* grid, int64_t slice_rows) {
+  if (validate(grid) || slice_rows < 1) return -1;
+  if (grid->n_features != 2 || grid->dim < 2 || grid->dim > 4) return -1;
+  Sched sched = make_sched(grid->n_levels, slice_rows, 128 * kSignalChunks);
+  sched.affinity = 1;
+  return signal_blocks_per_slice(sched);
+}
+
+extern "C" int mri_hashgrid_forward_signal(const mri_grid_desc* grid, const float* x, int64_t n,
+                                           const float* table, float* out, int64_t out_ld,
+                                           int64_t slice_rows, uint64_t* ready, void* stream) {
+  if (int rc = validate(grid)) return rc;
+  MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
+  MRI_REQUIRE(slice_rows >= 1, "slice_rows %lld", (long long)slice_rows);
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && table && out && ready && out_ld >= n, "NULL device pointer / short leading dimension");
+  const LevelTab tab = make_tab(grid);
+  Sched sched = make_sched(grid->n_levels, slice_rows, 128 * kSignalChunks);
+  sched.affinity = 1;  // the block order inside a slice is the XCD-aware one
+  const int64_t slices = ceil_div(n, slice_rows);
+  MRI_REQUIRE(slices * signal_blocks_per_slice(sched) < (1ll << 31), "grid too large");
+  return dispatch<FwdSignalLaunch>(grid->dim, grid->n_features, tab, sched, slice_rows,
+                                   (int)slices, x, n, table, out, out_ld,
+                                   reinterpret_cast<unsigned long long*>(ready),
+                                   (hipStream_t)stream);
+}

@@ -49,7 +49,32 @@ struct FusedArgs {
   float grad_scale;    // 2 / (n * grad_divisor)
   int stagger;         // team kernel: segments team 1 runs behind team 0
   float inv_n;
+  // team kernel, optional: x is being PRODUCED by a kernel running beside this one (the
+  // signalling hash-grid lookup of hashgrid.hip); slice r = the rows round r of the workgroups
+  // reads, complete when ready[r] >= ready_target
+  const unsigned long long* ready;
+  unsigned long long ready_target;
+  int* status;         // set to 1 if a wait gave up (the producer never arrived)
 };
+
+// Consumer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): ONE lane polls
+// with relaxed agent-scope loads, then ONE agent-scope acquire (invalidates this CU's L1) and
+// its vmcnt(0); the caller's workgroup barrier follows, after which plain loads see the
+// producer's write-through stores.  The poll is bounded (~1 s): a producer that never runs must
+// not hang the GPU -- the kernel then finishes on garbage and reports through `status`.
+__device__ __forceinline__ void wait_slice(const FusedArgs& a, int64_t slice) {
+  int spins = 0;
+  while (__hip_atomic_load(a.ready + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+         a.ready_target) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1 << 22)) {
+      __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // Segment timing for tools/mlp_segments.py (a tools-only build with -DMRI_MLP_PROFILE; the
 // shipped library compiles these to nothing): shader-clock cycles per barrier-separated segment,
@@ -604,6 +629,10 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     }
     dx_m0 = -1;
   };
+  if (a.ready) {  // the first round's rows exist
+    if (threadIdx.x == 0) wait_slice(a, 0);
+    __syncthreads();
+  }
   float4 x_next = load_x(tile_of(0) * kTeamTile, tid);  // beyond n -> zeros
   float t_next = load_t(tile_of(0) * kTeamTile, tid);
 
@@ -619,6 +648,8 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     int tid_opaque = tid_outer;
     asm volatile("" : "+v"(tid_opaque));
     const int tid = tid_opaque, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    // the rows prefetched below (round r + 1) must have been produced
+    if (a.ready && r + 1 < rounds && threadIdx.x == 0) wait_slice(a, r + 1);
     PROF_SYNC(0)  // S0
     {
       const int k = tid / (kTeamTile / 4), c4 = (tid % (kTeamTile / 4)) * 4;
@@ -970,13 +1001,20 @@ extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int
   return dispatch(a, hidden, false, pick_blocks(hidden, n), (hipStream_t)stream);
 }
 
+struct Overlap {
+  const unsigned long long* ready = nullptr;
+  unsigned long long target = 0;
+  int* status = nullptr;
+};
+
 static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const float* x, const float* target, int64_t n, int32_t k_in,
                                   int32_t hidden, const float* w1, const float* b1,
                                   const float* w2, const float* b2, const float* w3,
                                   const float* b3, float grad_divisor, float* d_w1, float* d_b1,
                                   float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
                                   float* loss_out, float* y, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+                                  int64_t workspace_bytes, void* stream,
+                                  const Overlap& overlap = Overlap()) {
   MRI_REQUIRE(supported(k_in, hidden, 1), "tiny MLP %d -> %d -> %d -> 1 is not supported", k_in,
               hidden, hidden);
   MRI_REQUIRE(n >= 0 && grad_divisor > 0.f, "bad n / grad_divisor");
@@ -999,6 +1037,7 @@ static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const
   a.grad_scale = (float)(2.0 / ((double)n_total * (double)grad_divisor));
   a.inv_n = (float)(1.0 / (double)n_total);
   a.stagger = std::min(std::max(options().mlp_stagger, 0), 8);
+  a.ready = overlap.ready, a.ready_target = overlap.target, a.status = overlap.status;
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
   r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7, r.overwrite = overwrite;
@@ -1050,6 +1089,33 @@ extern "C" int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const floa
   return tiny_mlp_train_impl(overwrite ? 1 : 0, x_ld, n_total, x, target, n, k_in, hidden, w1, b1,
                              w2, b2, w3, b3, grad_divisor, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x,
                              loss_out, y, workspace, workspace_bytes, stream);
+}
+
+extern "C" int64_t mri_tiny_mlp_round_rows(int32_t k_in, int32_t hidden, int64_t n) {
+  // rows one round of the training kernel's workgroups consumes (the team kernel only)
+  if (!supported(k_in, hidden, 1) || hidden != 128 || n < 1) return 0;
+  return (int64_t)pick_blocks(hidden, n) * 2 * kTeamTile;
+}
+
+extern "C" int mri_tiny_mlp_train_overlapped(const float* x, const float* target, int64_t n,
+                                             int32_t k_in, int32_t hidden, const float* w1,
+                                             const float* b1, const float* w2, const float* b2,
+                                             const float* w3, const float* b3, float grad_divisor,
+                                             float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                             float* d_w3, float* d_b3, float* d_x, float* loss_out,
+                                             int32_t overwrite, const uint64_t* ready,
+                                             uint64_t ready_target, int32_t* status,
+                                             void* workspace, int64_t workspace_bytes,
+                                             void* stream) {
+  MRI_REQUIRE(mri_tiny_mlp_round_rows(k_in, hidden, n) > 0,
+              "the overlapped decoder step needs the 128-wide kernel");
+  MRI_REQUIRE(ready && status, "NULL ready / status pointer");
+  Overlap o;
+  o.ready = reinterpret_cast<const unsigned long long*>(ready);
+  o.target = ready_target, o.status = status;
+  return tiny_mlp_train_impl(overwrite ? 1 : 0, n, n, x, target, n, k_in, hidden, w1, b1, w2, b2,
+                             w3, b3, grad_divisor, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x,
+                             loss_out, nullptr, workspace, workspace_bytes, stream, o);
 }
 
 #ifdef MRI_MLP_PROFILE

@@ -428,6 +428,51 @@ def tiny_mlp_train_slice(x_fm, target, col_offset: int, n: int, params, grads, l
     return loss_out
 
 
+# ----------------------------------------------------------- lookup and decoder side by side
+def tiny_mlp_round_rows(k_in: int, hidden: int, n: int) -> int:
+    """Rows one round of the decoder kernel's workgroups reads (0: no overlapped form)."""
+    return int(_lib.load().mri_tiny_mlp_round_rows(k_in, hidden, n))
+
+
+def hashgrid_signal_blocks(desc: GridDesc, slice_rows: int) -> int:
+    """What mri_hashgrid_forward_signal adds to a slice's counter (-1: unsupported grid)."""
+    return int(_lib.load().mri_hashgrid_forward_signal_blocks(C.byref(desc), slice_rows))
+
+
+def hashgrid_forward_signal(desc: GridDesc, x, table, out_fm, slice_rows: int, ready):
+    """Feature-major lookup on the CURRENT stream that reports finished slices in `ready`
+    (uint64 counters, one per slice of `slice_rows` coordinates, never reset by the library)."""
+    _gpu(x, table, out_fm)
+    x = _rowmajor(x).contiguous()
+    n = x.shape[0]
+    if out_fm.shape[0] != desc.n_levels * desc.n_features or out_fm.shape[1] < n \
+            or not out_fm.is_contiguous():
+        raise ValueError("out_fm must be a contiguous (L*F, >= n) block")
+    if ready.dtype != torch.int64 or ready.numel() * slice_rows < n:
+        raise ValueError("ready: one int64 counter per slice")
+    _lib.call("mri_hashgrid_forward_signal", C.byref(desc), _ptr(x), n, _ptr(table), _ptr(out_fm),
+              out_fm.shape[1], slice_rows, C.c_void_p(ready.data_ptr()), _stream())
+    return out_fm
+
+
+def tiny_mlp_train_overlapped(x_fm, target, params, grads, loss_out, d_x, ready, ready_target: int,
+                              status, grad_divisor: float = 1.0, overwrite: bool = True):
+    """tiny_mlp_train whose workgroups wait for the producer of x_fm (hashgrid_forward_signal,
+    queued earlier on ANOTHER stream) slice by slice."""
+    (w1, b1), (w2, b2), (w3, b3) = params
+    (g1, gb1), (g2, gb2), (g3, gb3) = grads
+    _gpu(x_fm, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_x)
+    k_in, n = x_fm.shape
+    ws = _tiny_workspace(k_in, w1.shape[0], n, x_fm.device)
+    _lib.call("mri_tiny_mlp_train_overlapped", _ptr(x_fm), _ptr(target), n, k_in, w1.shape[0],
+              _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor),
+              _ptr(g1), _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3), _ptr(d_x),
+              _ptr(loss_out), 1 if overwrite else 0, C.c_void_p(ready.data_ptr()),
+              C.c_uint64(ready_target), C.c_void_p(status.data_ptr()), _ptr(ws), ws.numel() * 4,
+              _stream())
+    return loss_out
+
+
 # --------------------------------------------------------------------------- fused SIREN chain
 def siren_supported(dim_in: int, hidden: int, n_sine_layers: int, dim_out: int) -> bool:
     return bool(_lib.load().mri_siren_supported(dim_in, hidden, n_sine_layers, dim_out))

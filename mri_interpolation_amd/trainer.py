@@ -114,6 +114,21 @@ class FusedStep:
         self.split_fraction = 0.0
         self._side2 = None
         self._split_rows = 0
+        # Fused decoder, optional: the lookup runs BESIDE the decoder kernel (its own stream); the
+        # decoder's workgroups wait per round for the slice of rows they are about to read
+        # (ops.hashgrid_forward_signal / tiny_mlp_train_overlapped): one decoder launch, none of
+        # the fixed costs of the two-slice form above.  Bit-identical results, but measured SLOWER
+        # at BASELINE config 4 (0.87 against 0.66 ms per step): f32 MFMAs execute on the vector
+        # ALUs, so beside the decoder's two MFMA waves per SIMD the lookup's ~150 vector
+        # instructions per (coordinate, level) barely issue, and the 64 registers the decoder leaves
+        # free hold 2 lookup waves per SIMD instead of 8 -- the lookup takes 0.49 ms instead of
+        # 0.10 and the decoder waits for it.  Off by default.
+        self.overlap_forward = False
+        self._ready = None       # uint64 slice counters: only ever grow
+        self._ready_total = 0    # what a complete slice's counter holds after this step
+        self._ready_key = None
+        self._status = None
+        self._overlapped = False
 
     def _tiny_mlp_plan(self):
         """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
@@ -189,6 +204,18 @@ class FusedStep:
         n = coords.shape[0]
         ws = self._workspace(n, train)
         x, feature_major = coords, False
+        self._overlapped = False
+        if self.encoder is not None and train and self.use_tiny and self._overlap_plan(n):
+            # lookup on its own stream, queued BEFORE the decoder (which backward() queues on the
+            # main stream and which waits for the slices through the ready counters)
+            self._side2.wait_stream(torch.cuda.current_stream())  # coordinates, tables, buffers
+            with torch.cuda.stream(self._side2):
+                with self._phase("hashgrid_fwd"):
+                    ops.hashgrid_forward_signal(self.encoder.desc, coords, self.encoder.table.data,
+                                                ws["enc"], self._ready_key[1], self._ready)
+            self._ready_total += self._ready_expected
+            self._overlapped = True
+            return ws["enc"], ws
         if self.encoder is not None:
             h = 0
             if train and self.use_tiny and self.split_fraction > 0 and n >= 4096:
@@ -237,6 +264,33 @@ class FusedStep:
             self._bwd_ws = torch.empty((need + 7) // 8, dtype=torch.int64,
                                        device=self.flat.param.device)
         return self._bwd_ws
+
+    def _overlap_plan(self, n: int) -> bool:
+        """Prepare the slice counters of the side-by-side lookup for a batch of n rows."""
+        if not self.overlap_forward or self.split_fraction > 0:
+            return False
+        k_in, hidden = self.layers[0].weight.shape[1], self.layers[0].weight.shape[0]
+        rows = ops.tiny_mlp_round_rows(k_in, hidden, n)
+        expected = ops.hashgrid_signal_blocks(self.encoder.desc, rows) if rows > 0 else -1
+        if rows <= 0 or expected <= 0:
+            self.overlap_forward = False  # other decoder widths / grids: lookup first, as before
+            return False
+        if self._ready_key != (n, rows):
+            dev = self.flat.param.device
+            if self._ready is not None:
+                torch.cuda.synchronize(dev)  # nobody may still be counting on the old layout
+            self._ready = torch.zeros(-(-n // rows), dtype=torch.int64, device=dev)
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._ready_total, self._ready_key, self._ready_expected = 0, (n, rows), expected
+            if self._side2 is None:
+                self._side2 = torch.cuda.Stream(device=dev)
+        return True
+
+    def check_status(self):
+        """Raise if a decoder workgroup ever gave up waiting for the lookup (synchronises)."""
+        if self._status is not None and int(self._status.item()) != 0:
+            raise RuntimeError("fused step: the decoder kernel timed out waiting for the hash-grid "
+                               "lookup running beside it (results of that step are invalid)")
 
     def _level_buckets(self):
         """[(level mask, flat-gradient slice)] in execution order for the current bucket count
@@ -322,7 +376,12 @@ class FusedStep:
                 h, n = self._split_rows, coords.shape[0]
                 if not first:
                     self.loss.zero_()  # the kernels add to it: keep it this batch's loss
-                if h:
+                if self._overlapped:
+                    ops.tiny_mlp_train_overlapped(ws["enc"], target, self.tiny["params"],
+                                                  self.tiny["grads"], self.loss, ws["d_enc"],
+                                                  self._ready, self._ready_total, self._status,
+                                                  grad_divisor=div, overwrite=first)
+                elif h:
                     if self._side2 is None:
                         self._side2 = torch.cuda.Stream(device=coords.device)
                     self._side2.wait_stream(torch.cuda.current_stream())  # starts with slice 1's decoder

@@ -202,6 +202,64 @@ def test_full_size_cfg3_siren_intensities_and_step(amd):
         assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), 5e-5, f"gb{i}")
 
 
+# ------------------------------------------------------- lookup and decoder running side by side
+@pytest.mark.parametrize("dim,n", [(3, 1 << 18), (3, 100001), (3, 5000), (3, 33), (4, 70000), (2, 40000)])
+def test_overlapped_lookup_and_decoder_equal_the_sequential_step(amd, dim, n):
+    """The hash-grid lookup runs on its own stream BESIDE the decoder kernel, which waits slice by
+    slice on agent-scope counters (mri_hashgrid_forward_signal / mri_tiny_mlp_train_overlapped):
+    same features, loss, gradients and parameters as lookup-then-decoder, bit for bit, over
+    several steps (the counters only ever grow), for full, ragged and sub-slice batches."""
+    torch.manual_seed(dim * 1000 + n % 997)
+    net = amd.models.HashMLP(dim, 16, 2, 17, 16, 512, dim_hidden=128, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
+                             lr=5e-3)
+    with torch.no_grad():
+        net.encoder.table.uniform_(-0.5, 0.5)
+    nets = [net.cuda(), copy.deepcopy(net).cuda()]
+    steps = [amd.trainer.FusedStep(q, q.configure_optimizers()) for q in nets]
+    steps[0].overlap_forward = True   # off by default: measured slower (DESIGN.md 4.7)
+    assert not steps[1].overlap_forward
+    g = torch.Generator().manual_seed(n)
+    for k in range(4):
+        x, y = torch.rand(n, dim, generator=g).cuda(), torch.rand(n, 1, generator=g).cuda()
+        la, lb = steps[0].train_step(x, y), steps[1].train_step(x, y)
+        torch.cuda.synchronize()
+        assert steps[0]._overlapped and not steps[1]._overlapped
+        assert torch.equal(steps[0]._ws[(n, True)]["enc"], steps[1]._ws[(n, True)]["enc"]), k
+        assert float(la) == float(lb)
+        assert torch.equal(steps[0].flat.grad, steps[1].flat.grad), k
+        assert torch.equal(steps[0].flat.param, steps[1].flat.param), k
+    steps[0].check_status()
+    # a different batch size re-plans the slices
+    x, y = torch.rand(n + 777, dim, device="cuda"), torch.rand(n + 777, 1, device="cuda")
+    la, lb = steps[0].train_step(x, y), steps[1].train_step(x, y)
+    assert float(la) == float(lb) and torch.equal(steps[0].flat.param, steps[1].flat.param)
+    steps[0].check_status()
+
+
+def test_overlapped_decoder_gives_up_instead_of_hanging(amd):
+    """A producer that never arrives: the decoder's bounded wait ends, the kernel finishes and
+    reports through the status word (the GPU must never hang on a missing launch)."""
+    net = amd.models.HashMLP(3, 4, 2, 12, 4, 32, dim_hidden=128, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False).cuda()
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    step.overlap_forward = True
+    n = 4096
+    x, y = torch.rand(n, 3, device="cuda"), torch.rand(n, 1, device="cuda")
+    step.train_step(x, y)
+    step.check_status()
+    ws = step._ws[(n, True)]
+    import time
+    t0 = time.time()
+    amd.ops.tiny_mlp_train_overlapped(ws["enc"], y, step.tiny["params"], step.tiny["grads"], step.loss,
+                                      ws["d_enc"], step._ready, step._ready_total + 10 ** 6,
+                                      step._status)   # a target nobody will ever reach
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30.0
+    with pytest.raises(RuntimeError, match="timed out"):
+        step.check_status()
+
+
 # --------------------------------------------------------------------- fused SIREN chain kernels
 def _load_siren(amd, m):
     net = amd.models.SirenNet(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], lr=m.get("lr", 1e-4))
