@@ -50,37 +50,63 @@ struct ChainArgs {
   float* y;                         // (n)
 };
 
+// Geometry of a chain workgroup: ROWS-row tiles, ROWS / 32 row blocks x 4 column blocks of
+// 32 x 64 per wave (ROWS * 8 threads), weight chunks KC deep.  Two shapes are built:
+//   <64, 32>  one 512-thread workgroup per CU (151 KiB of LDS)
+//   <32, 16>  two 256-thread workgroups per CU (75 KiB each): the two waves of a SIMD then belong
+//             to different workgroups, walk different tiles and do not meet at each other's
+//             barriers, so one's waits (DMA landing, LDS latency, barriers: a third of a wave's
+//             cycles) fall beside the other's MFMAs instead of beside its waits; the price is
+//             twice the weight traffic from L2 (each 32-row tile streams all of W).
+template <int ROWS, int KC>
+struct Geo {
+  static constexpr int rows = ROWS, kc = KC;
+  static constexpr int waves = ROWS / 32 * 4, threads = waves * 64;
+  static constexpr int chunks = kH / KC;             // per layer
+  static constexpr int slots = KC / 4;               // 16-byte slots per chunk row
+  static constexpr int piece_rows = 256 / slots;     // rows of W per 1-KiB DMA instruction
+  static constexpr int pieces_per_wave = KC / waves; // kH * KC * 4 B / 1 KiB / waves
+  static constexpr int swz_shift = slots == 8 ? 1 : 2;  // rows a bank row of 16 slots spans
+  static constexpr int octets = KC / 8;
+  static constexpr int drip_regs = 16 / chunks > 0 ? 16 / chunks : 1;  // per tile and chunk
+  static_assert(KC % waves == 0 && (slots == 8 || slots == 4), "unsupported chain geometry");
+};
+
+template <class G>
 struct Smem {
-  float wbuf[2][kH * kKc];          // weight chunks [n][32] with 16-byte slots XOR-swizzled
-  float img[kRows * kLd];           // activation image of the tile
-  float xs[kRows * kMaxIn];
+  float wbuf[2][kH * G::kc];        // weight chunks [n][KC] with 16-byte slots XOR-swizzled
+  float img[G::rows * kLd];         // activation image of the tile
+  float xs[G::rows * kMaxIn];
   float bias[kMaxSine][kH];
-  float w_first[kH * kMaxIn];
   float w_last[kH];
 };
 
 // row of register r of a 32x32 accumulator: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-// Queue the LDS-DMA of chunk (weights w of one layer, columns [32 kc, 32 kc + 32)) into `dst`:
-// 32 pieces of 8 rows x 128 B, four per wave; lane = (row in piece, 16-byte slot); the slot a
-// lane FETCHES is its LDS slot XOR ((row >> 1) & 7), the involution the fragment reads undo.
+// Queue the LDS-DMA of chunk (weights w of one layer, columns [KC kc, KC kc + KC)) into `dst`:
+// pieces of 1 KiB (piece_rows rows x KC floats), lane = (row in piece, 16-byte slot); the slot a
+// lane FETCHES is its LDS slot XOR f(row), the involution the fragment reads undo, with
+// f(n) = (n >> swz_shift) & (slots - 1): the 16 rows a ds_read_b128 lane group touches then fall
+// on 16 different 16-byte slots of the 256-byte bank row.
+template <class G>
 __device__ __forceinline__ void issue_chunk(const float* __restrict__ w, int kc, float* dst,
                                             int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;
-    const int n = piece * 8 + (lane >> 3);
-    const int q = (lane & 7) ^ ((n >> 1) & 7);
+  for (int i = 0; i < G::pieces_per_wave; ++i) {
+    const int piece = wave * G::pieces_per_wave + i;
+    const int n = piece * G::piece_rows + lane / G::slots;
+    const int q = (lane % G::slots) ^ ((n >> G::swz_shift) & (G::slots - 1));
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(w + n * kH + kc * kKc + q * 4),
-        (__attribute__((address_space(3))) void*)(dst + piece * 8 * kKc), 16, 0, 0);
+        (const __attribute__((address_space(1))) void*)(w + n * kH + kc * G::kc + q * 4),
+        (__attribute__((address_space(3))) void*)(dst + piece * G::piece_rows * G::kc), 16, 0, 0);
   }
 }
 
-// One 32-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x 64 tile.
+// One KC-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x 64 tile.
 // Lane half lh takes k = 8 j + 4 lh + e of octet j (element e of its 16-byte fragment): the two
 // halves of an MFMA's 2-deep contraction are k and k + 4.
+template <class G>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[2], const float* __restrict__ a_row,
                                           const float* __restrict__ wb, int nb0, int nb1,
                                           int sw0, int sw1, int lh) {
@@ -102,17 +128,35 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[2], const float* __restr
   };
   fetch(0, 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j + 1 < 4) fetch((j + 1) & 1, j + 1);
+  for (int j = 0; j < G::octets; ++j) {
+    if (j + 1 < G::octets) fetch((j + 1) & 1, j + 1);
     __builtin_amdgcn_sched_barrier(0);
     compute(j & 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <bool STORE>
-__global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs a) {
-  __shared__ Smem sm;
+// Phase timing for tools/siren_phases.py (a tools-only build with -DSIREN_PROFILE; the shipped
+// library compiles these to nothing): shader-clock cycles per phase of the forward kernel, per wave.
+#ifdef SIREN_PROFILE
+__device__ long long* g_siren_profile = nullptr;
+#define SP_BEGIN long long sp_t = clock64(); long long sp_acc[8] = {};
+#define SP_MARK(i) { const long long sp_n = clock64(); sp_acc[i] += sp_n - sp_t; sp_t = sp_n; }
+#define SP_END                                                                         \
+  if (g_siren_profile && (threadIdx.x & 63) == 0) {                                    \
+    long long* dst = g_siren_profile + ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8; \
+    for (int q = 0; q < 8; ++q) dst[q] = sp_acc[q];                                    \
+  }
+#else
+#define SP_BEGIN
+#define SP_MARK(i)
+#define SP_END
+#endif
+
+template <bool STORE, class G>
+__global__ __launch_bounds__(G::threads, 2) void siren_forward_kernel(const ChainArgs a) {
+  __shared__ Smem<G> sm;
+  constexpr int kThreadsG = G::threads;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -120,31 +164,28 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
   const int n_mm = a.n_sine - 1;  // 256 x 256 layers
 
   // ---- small resident parameters ------------------------------------------------------------
-  for (int e = tid; e < kH * kMaxIn; e += kThreads) {
-    const int o = e / kMaxIn, d = e % kMaxIn;
-    sm.w_first[e] = d < a.dim_in ? a.w[0][o * a.dim_in + d] : 0.f;
-  }
   for (int l = 0; l < a.n_sine; ++l)
-    for (int e = tid; e < kH; e += kThreads) sm.bias[l][e] = a.b[l][e];
-  for (int e = tid; e < kH; e += kThreads) sm.w_last[e] = a.w[a.n_sine][e];
+    for (int e = tid; e < kH; e += kThreadsG) sm.bias[l][e] = a.b[l][e];
+  for (int e = tid; e < kH; e += kThreadsG) sm.w_last[e] = a.w[a.n_sine][e];
   const float b_last = a.b[a.n_sine][0];
 
-  const int64_t tiles = (a.n + kRows - 1) / kRows;
+  const int64_t tiles = (a.n + G::rows - 1) / G::rows;
   // this lane's fragment addresses
   const float* a_row = sm.img + (rb * 32 + l31) * kLd + 4 * lh;
   const int n0 = cb * 64 + l31, n1 = n0 + 32;
-  const int nb0 = n0 * kKc, nb1 = n1 * kKc, sw0 = (n0 >> 1) & 7, sw1 = (n1 >> 1) & 7;
+  const int nb0 = n0 * G::kc, nb1 = n1 * G::kc;
+  const int sw0 = (n0 >> G::swz_shift) & (G::slots - 1), sw1 = (n1 >> G::swz_shift) & (G::slots - 1);
 
-  // chunk stream: chunk s (layer 1 + (s / 8) % n_mm, columns 32 (s % 8)) lives in wbuf[s & 1]
+  // chunk stream: chunk s (layer 1 + (s / chunks) % n_mm, columns KC (s % chunks)) lives in wbuf[s & 1]
   int s = 0;
-  if (n_mm > 0 && (int64_t)blockIdx.x < tiles) issue_chunk(a.w[1], 0, sm.wbuf[0], wave, lane);
+  if (n_mm > 0 && (int64_t)blockIdx.x < tiles) issue_chunk<G>(a.w[1], 0, sm.wbuf[0], wave, lane);
 
   // activations waiting to leave for HBM (STORE): the outputs of MFMA layer `pend_l` of the tile
-  // at `pend_m0`, dripped out two registers per tile and chunk beside the next layer's MFMAs
+  // at `pend_m0`, dripped out a few registers per chunk beside the next layer's MFMAs
   float pa[2][16], pd[2][16];
   int pend_l = -1;
   int64_t pend_m0 = 0;
-  // lane's element offset inside a tile's (64, H) block for accumulator register 0 of tile 0
+  // lane's element offset inside a tile's (ROWS, H) block for accumulator register 0 of tile 0
   const int lane_off = (rb * 32 + 4 * lh) * kH + cb * 64 + l31;
   auto drip = [&](int r_lo, int r_hi, bool tile_full) {
     if (!STORE || pend_l < 0) return;
@@ -168,23 +209,26 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
       }
   };
 
+  SP_BEGIN
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t m0 = tile * kRows;
-    const bool full_tile = m0 + kRows <= a.n;  // wave-uniform: stores need no per-lane row check
+    const int64_t m0 = tile * G::rows;
+    const bool full_tile = m0 + G::rows <= a.n;  // wave-uniform: stores need no per-lane row check
     // ---- x tile -> LDS -------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // previous tile is done with img / xs
-    if (tid < kRows * kMaxIn) {
+    if (tid < G::rows * kMaxIn) {
       const int row = tid / kMaxIn, d = tid % kMaxIn;
       sm.xs[tid] = (d < a.dim_in && m0 + row < a.n) ? a.x[(m0 + row) * a.dim_in + d] : 0.f;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // ---- first layer on the VALU: thread <-> (column, half of the rows) -----------------------
+    SP_MARK(0)  // tile top: x tile
+    // ---- first layer on the VALU: thread <-> (column, 32 of the rows) --------------------------
     {
       const int col = tid & (kH - 1), r0 = (tid >> 8) * 32;
       float wr[kMaxIn];
 #pragma unroll
-      for (int d = 0; d < kMaxIn; ++d) wr[d] = sm.w_first[col * kMaxIn + d];
+      for (int d = 0; d < kMaxIn; ++d) wr[d] = d < a.dim_in ? a.w[0][col * a.dim_in + d] : 0.f;
       const float bias = sm.bias[0][col];
       float* __restrict__ ga = STORE ? a.act[0] : nullptr;
       float* __restrict__ gd = STORE ? a.deriv[0] : nullptr;
@@ -209,29 +253,35 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
         }
       }
     }
+    SP_MARK(1)  // first layer
     // ---- 256 x 256 layers ----------------------------------------------------------------------
     for (int l = 1; l <= n_mm; ++l) {
       f32x16 acc[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][r] = 0.f, acc[1][r] = 0.f;
 #pragma unroll
-      for (int kc = 0; kc < kChunks; ++kc, ++s) {
+      for (int kc = 0; kc < G::chunks; ++kc, ++s) {
         // Chunk s has landed (this wave's own pieces; vmcnt counts loads, stores and LDS-DMA
         // together).  The stores dripped at the start of the previous chunk have had a whole
-        // chunk (~2 us) to retire, so waiting for everything costs nothing: counted waits that
-        // left them in flight measured 6.27 against 6.29 ms per 2^20-row pass.
+        // chunk to retire, so waiting for everything costs nothing: counted waits that left them
+        // in flight measured 6.27 against 6.29 ms per 2^20-row pass.
+#ifndef SIREN_EXPERIMENT_NO_DMA_WAIT  // timing experiment only (results are then wrong)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... for every wave, and wbuf[(s + 1) & 1] is free
+        SP_MARK(2)  // chunk wait + barrier
         {
-          const bool more_k = kc + 1 < kChunks;
+          const bool more_k = kc + 1 < G::chunks;
           const int nl = more_k ? l : (l < n_mm ? l + 1 : 1);
           if (more_k || l < n_mm || tile + gridDim.x < tiles)
-            issue_chunk(a.w[nl], more_k ? kc + 1 : 0, sm.wbuf[(s + 1) & 1], wave, lane);
+            issue_chunk<G>(a.w[nl], more_k ? kc + 1 : 0, sm.wbuf[(s + 1) & 1], wave, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        drip(2 * kc, 2 * kc + 2, full_tile);
-        mma_chunk(acc, a_row + kc * kKc, sm.wbuf[s & 1], nb0, nb1, sw0, sw1, lh);
+        if (G::chunks <= 16) drip(kc * 16 / G::chunks, (kc + 1) * 16 / G::chunks, full_tile);
+        SP_MARK(3)  // DMA issue + dripped stores
+        mma_chunk<G>(acc, a_row + kc * G::kc, sm.wbuf[s & 1], nb0, nb1, sw0, sw1, lh);
+        SP_MARK(4)  // fragment reads + MFMAs
       }
       pend_l = -1;  // fully dripped
       // ---- epilogue: bias, w0, sincos; the image becomes this layer's output -------------------
@@ -247,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
           pa[t][r] = s0, pa[t][r + 1] = s1;
           pd[t][r] = w0 * c0, pd[t][r + 1] = w0 * c1;
         }
+      SP_MARK(5)  // epilogue arithmetic
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave has read the image for the last time
 #pragma unroll
@@ -261,6 +312,7 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
           pend_l = -1;
         }
       }
+      SP_MARK(6)  // epilogue barrier + image write
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // image complete
@@ -268,8 +320,8 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
     {
       const float4 wv = *reinterpret_cast<const float4*>(sm.w_last + 4 * lane);
 #pragma unroll
-      for (int i = 0; i < kRows / 8; ++i) {
-        const int row = wave * (kRows / 8) + i;
+      for (int i = 0; i < G::rows / G::waves; ++i) {
+        const int row = wave * (G::rows / G::waves) + i;
         const float4 xv = *reinterpret_cast<const float4*>(sm.img + row * kLd + 4 * lane);
         float acc1 = xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
 #pragma unroll
@@ -277,7 +329,9 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
         if (lane == 0 && m0 + row < a.n) a.y[m0 + row] = acc1 + b_last;
       }
     }
+    SP_MARK(7)  // head
   }
+  SP_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -750,13 +804,22 @@ extern "C" int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int3
       MRI_REQUIRE(act[l] && deriv[l], "NULL activation buffer (layer %d)", l);
       a.act[l] = act[l], a.deriv[l] = deriv[l];
     }
-  const int blocks = (int)std::min<int64_t>(ceil_div(n, kRows), 256);  // one workgroup per CU
-  if (act)
-    hipLaunchKernelGGL((siren_forward_kernel<true>), dim3(blocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((siren_forward_kernel<false>), dim3(blocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (options().siren_two_per_cu) {  // two 256-thread workgroups per CU, 32-row tiles
+    using G = Geo<32, 16>;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, G::rows), 512);
+    if (act)
+      hipLaunchKernelGGL((siren_forward_kernel<true, G>), dim3(blocks), dim3(G::threads), 0, st, a);
+    else
+      hipLaunchKernelGGL((siren_forward_kernel<false, G>), dim3(blocks), dim3(G::threads), 0, st, a);
+  } else {  // one 512-thread workgroup per CU, 64-row tiles
+    using G = Geo<64, 32>;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, G::rows), 256);
+    if (act)
+      hipLaunchKernelGGL((siren_forward_kernel<true, G>), dim3(blocks), dim3(G::threads), 0, st, a);
+    else
+      hipLaunchKernelGGL((siren_forward_kernel<false, G>), dim3(blocks), dim3(G::threads), 0, st, a);
+  }
   return check_launch("siren_forward_kernel");
 }
 
@@ -822,3 +885,12 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   }
   return MRI_OK;
 }
+
+#ifdef SIREN_PROFILE
+extern "C" int mri_debug_set_siren_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mri::g_siren_profile), &device_buffer, sizeof(device_buffer)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#endif

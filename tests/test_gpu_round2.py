@@ -433,6 +433,26 @@ def test_hashmlp_gelu_notebook_decoder(amd, path):
                          fx[f"table_{s}_{l}"], REL_TOL, f"table {l} step {s}")
 
 
+# --------------------------------------------------------------- whole-step seeds at the ReLU kink
+@pytest.mark.parametrize("seed", [1495, 2477, 3633])
+def test_relu_kink_seeds_are_fully_explained(amd, seed):
+    """tools/fuzz.py found these whole hash + tiny-MLP steps (7 of 4,000 seeds) whose gradients
+    miss 1e-5 against the oracle: ONE hidden pre-activation of ONE coordinate is ~1e-9 (exactly 0
+    for seed 3633), seven orders below typical, so oracle and kernel -- two f32 summation orders --
+    sit on different sides of the ReLU kink.  The claim is checked, not assumed: the oracle
+    re-evaluated with that single gate flipped must match EVERY gradient tensor of the kernel to
+    1e-5 (tools/fuzz.py::explain_relu_kink).  On a host whose f32 sums round the other way the
+    step simply matches; anything else fails."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz
+    import mri_interpolation_amd as pkg
+    case, errs, note = fuzz.run_step(seed, pkg)
+    print(f"seed {seed}: {case}: {note or 'matches the oracle directly'}")
+    assert errs["loss"] <= fuzz.TOL and errs["grads"] <= fuzz.TOL, (errs, note)
+    assert note is None or note.startswith("ReLU kink: coordinate")
+
+
 # ------------------------------------------------------------------------ gradient accumulation
 @pytest.mark.parametrize("kind", ["hash_tiny", "siren"])
 def test_gradient_accumulation_equals_one_step_on_the_union(amd, kind):
