@@ -64,12 +64,13 @@ struct Geo {
   static constexpr int waves = ROWS / 32 * 4, threads = waves * 64;
   static constexpr int chunks = kH / KC;             // per layer
   static constexpr int slots = KC / 4;               // 16-byte slots per chunk row
-  static constexpr int piece_rows = 256 / slots;     // rows of W per 1-KiB DMA instruction
+  static constexpr int piece_rows = 64 / slots;      // rows of W per 1-KiB DMA instruction (64 lanes x 16 B)
   static constexpr int pieces_per_wave = KC / waves; // kH * KC * 4 B / 1 KiB / waves
   static constexpr int swz_shift = slots == 8 ? 1 : 2;  // rows a bank row of 16 slots spans
   static constexpr int octets = KC / 8;
   static constexpr int drip_regs = 16 / chunks > 0 ? 16 / chunks : 1;  // per tile and chunk
   static_assert(KC % waves == 0 && (slots == 8 || slots == 4), "unsupported chain geometry");
+  static_assert(pieces_per_wave * waves * piece_rows == kH, "the DMA pieces must tile the chunk");
 };
 
 template <class G>
