@@ -224,6 +224,15 @@ int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, 
                              float* loss_out, float* y, int32_t overwrite, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* Gradient w.r.t. the COORDINATES: the reference detaches only the integer part of x * res
+ * (encoding.py:111-113), so autograd carries d out / d x through the interpolation weights:
+ * d_x[i][d] = res_d * sum over levels and corners of (+-1) prod_{e != d} w_e * <d_out, row>.
+ * Not on the training path (coordinates carry no gradient there); d_x is (n, D) row-major. */
+int mri_hashgrid_backward_input(const mri_grid_desc* grid, const float* x, const float* d_out,
+                                int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
+                                int64_t dout_feat_stride, const float* table, float* d_x,
+                                void* stream);
+
 /* ---- lookup and decoder running side by side ----------------------------------------------
  * The decoder kernel is bound by the f32 matrix rate and leaves the texture path idle; the lookup
  * is bound by the texture path, needs no LDS and 27 registers.  Launched on two streams they share

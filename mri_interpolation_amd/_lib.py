@@ -63,6 +63,7 @@ SIGNATURES = {
                            _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_tiny_mlp_train_overwrite": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "mri_hashgrid_backward_input": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
     "mri_hashgrid_forward_signal": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _P, _P],
     "mri_tiny_mlp_train_overlapped": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                       _P, _P, _P, _P, _P, _P, _I32, _P, C.c_uint64, _P, _P, _I64,

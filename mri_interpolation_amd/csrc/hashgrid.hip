@@ -281,6 +281,65 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_atomic_kernel(
   }
 }
 
+// ------------------------------------------------------------- gradient w.r.t. the coordinates
+// The reference keeps the path x -> xf = x res - trunc(x res) -> weights differentiable
+// (encoding.py:111-113,120-122: `.detach()` only on the integer part), so a caller that asks for
+// d out / d x gets  dx[d] = res_d * sum_levels sum_corners (+-1) prod_{e != d} w_e * <d_out, row>.
+// Nothing on the training path needs it (coordinates carry no gradient there): one thread per
+// coordinate walks all levels, no tuning beyond coalesced stores.
+template <int D, int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(
+    const LevelTab tab, int n_levels, const float* __restrict__ x, const float* __restrict__ d_out,
+    int64_t n, int64_t sl, int64_t sr, int64_t sf, const float* __restrict__ table,
+    float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+  for (int level = 0; level < n_levels; ++level) {
+    const uint32_t size = tab.size[level], magic = tab.magic[level];
+    const bool pow2 = tab.pow2[level] != 0;
+    const float* __restrict__ rows = table + tab.offset[level] * F;
+    const Cell<D> c = locate<D>(x, i, tab.res[level]);
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = d_out[(int64_t)level * sl + i * sr + f * sf];
+#pragma unroll kCornerUnroll<D>
+    for (int nb = 0; nb < (1 << D); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, nb, h, w);
+      const float* __restrict__ row = rows + (uint64_t)slot_of(h, size, magic, pow2) * F;
+      float dot = 0.0f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) dot += g[f] * row[f];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        float others = 1.0f;
+#pragma unroll
+        for (int e = 0; e < D; ++e)
+          if (e != d) others *= ((nb >> e) & 1) ? c.f[e] : 1.0f - c.f[e];
+        const float signed_w = ((nb >> d) & 1) ? others : -others;
+        acc[d] += (signed_w * dot) * tab.res[level][d];
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) dx[i * D + d] = acc[d];
+}
+
+template <int D, int F>
+struct BwdInputLaunch {
+  static int run(const LevelTab& tab, int n_levels, const float* x, const float* d_out, int64_t n,
+                 int64_t sl, int64_t sr, int64_t sf, const float* table, float* dx,
+                 hipStream_t st) {
+    hipLaunchKernelGGL((hashgrid_bwd_input_kernel<D, F>), dim3((unsigned)ceil_div(n, 256)),
+                       dim3(256), 0, st, tab, n_levels, x, d_out, n, sl, sr, sf, table, dx);
+    return check_launch("hashgrid_bwd_input_kernel");
+  }
+};
+
 Sched make_sched(int n_levels, int64_t n, int coords_per_block = 256) {
   Sched s{};
   s.affinity = options().xcd_affinity;
@@ -404,4 +463,19 @@ extern "C" int mri_hashgrid_forward_signal(const mri_grid_desc* grid, const floa
                                    (int)slices, x, n, table, out, out_ld,
                                    reinterpret_cast<unsigned long long*>(ready),
                                    (hipStream_t)stream);
+}
+
+extern "C" int mri_hashgrid_backward_input(const mri_grid_desc* grid, const float* x,
+                                           const float* d_out, int64_t n,
+                                           int64_t dout_level_stride, int64_t dout_row_stride,
+                                           int64_t dout_feat_stride, const float* table,
+                                           float* d_x, void* stream) {
+  if (int rc = validate(grid)) return rc;
+  MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && d_out && table && d_x, "NULL device pointer");
+  const LevelTab tab = make_tab(grid);
+  return dispatch<BwdInputLaunch>(grid->dim, grid->n_features, tab, grid->n_levels, x, d_out, n,
+                                  dout_level_stride, dout_row_stride, dout_feat_stride, table,
+                                  d_x, (hipStream_t)stream);
 }

@@ -123,7 +123,7 @@ class _HashGridBase(nn.Module):
             raise OverflowError("int too big to convert")
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        if torch.is_grad_enabled() and self.table.requires_grad:
+        if torch.is_grad_enabled() and (self.table.requires_grad or x2.requires_grad):
             out = ops.HashGridFunction.apply(x2, self.table, self.desc)
         else:
             out = ops.hashgrid_forward(self.desc, x2, self.table.detach())

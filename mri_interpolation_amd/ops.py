@@ -166,23 +166,44 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
     return d_table
 
 
+def hashgrid_backward_input(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
+                            table: torch.Tensor, feature_major: bool = False) -> torch.Tensor:
+    """d loss / d x (n, D): the reference keeps x -> x*res - trunc(x*res) differentiable
+    (encoding.py:111-113), so callers that track coordinates (e.g. spatial derivatives of the
+    implicit image) get their gradient; the training path never asks for it."""
+    _gpu(x, d_out, table)
+    x = _rowmajor(x).contiguous()
+    n = x.shape[0]
+    if not d_out.is_contiguous():
+        d_out = d_out.contiguous()
+    sl, sr, sf = _enc_strides(desc, n, feature_major)
+    dx = torch.empty_like(x)
+    _lib.call("mri_hashgrid_backward_input", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
+              _ptr(table), _ptr(dx), _stream())
+    return dx
+
+
 class HashGridFunction(torch.autograd.Function):
-    """Autograd node for the encoder: gradient flows to the table only (the reference's
-    coordinates never require grad; encoding.py:113 keeps that path but nothing uses it)."""
+    """Autograd node for the encoder: gradient to the table (the training path) and, when the
+    caller tracks the coordinates, to x (the reference keeps that path, encoding.py:113)."""
 
     @staticmethod
     def forward(ctx, x, table, desc):
         ctx.desc = desc
-        ctx.save_for_backward(x)
-        ctx.table_shape = table.shape
+        ctx.save_for_backward(x, table)
         return hashgrid_forward(desc, x, table)
 
     @staticmethod
     def backward(ctx, d_out):
-        (x,) = ctx.saved_tensors
-        d_table = torch.zeros(ctx.table_shape, device=d_out.device, dtype=torch.float32)
-        hashgrid_backward(ctx.desc, x, d_out.contiguous(), d_table)
-        return None, d_table, None
+        x, table = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        d_x = d_table = None
+        if ctx.needs_input_grad[1]:
+            d_table = torch.zeros(table.shape, device=d_out.device, dtype=torch.float32)
+            hashgrid_backward(ctx.desc, x, d_out, d_table)
+        if ctx.needs_input_grad[0]:
+            d_x = hashgrid_backward_input(ctx.desc, x, d_out, table).reshape(x.shape)
+        return d_x, d_table, None
 
 
 # --------------------------------------------------------------------------- linear layers

@@ -202,6 +202,48 @@ def test_full_size_cfg3_siren_intensities_and_step(amd):
         assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), 5e-5, f"gb{i}")
 
 
+# ------------------------------------------------------------------ gradient w.r.t. coordinates
+@pytest.mark.parametrize("name", ["enc_cfg4", "enc_cfg5_4d", "enc_defaults_2d", "enc_f4_small",
+                                  "enc_v2_notebook", "enc_v2_cfg5"])
+def test_encoder_coordinate_gradient(amd, name):
+    """`x.requires_grad_()` callers: the reference detaches only the integer part of x * res
+    (encoding.py:111-113), so autograd carries d out / d x through the interpolation weights.
+    Checked against torch autograd of the oracle's encoder (itself pinned by the same fixture's
+    forward values), edge rows included; the table gradient of the same backward pass too."""
+    fx = load_golden(name)
+    c = dict(fx.meta["ctor"])
+    cls = getattr(amd.encoding, c.pop("cls"))
+    dim = c.pop("dim")
+    for k in ("base_resolution", "finest_resolution"):
+        if isinstance(c.get(k), list):
+            c[k] = tuple(c[k])
+    enc = cls(dim, **c)
+    feats = enc.n_features_per_level
+    tabs = ohash.init_tables(enc.sizes, feats, fx.meta["table_seed"], fx.meta["table_scale"])
+    with torch.no_grad():
+        enc.table.copy_(torch.cat(tabs))
+    enc = enc.cuda()
+    res, _ = ohash.resolutions_for(dim, enc.n_levels, c.get("log2_hashmap_size", 15),
+                                   c.get("base_resolution", 16), c.get("finest_resolution", 512))
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    d_out = torch.from_numpy(fx["d_out"])
+    for t in tabs:
+        t.requires_grad_(True)
+    ohash.encode(x, tabs, res).backward(d_out)
+    xg = cuda(fx["x"]).requires_grad_(True)
+    out = enc(xg)
+    out.backward(d_out.cuda())
+    assert xg.grad is not None and xg.grad.shape == xg.shape
+    assert_close(xg.grad.cpu().numpy(), x.grad.numpy(), REL_TOL, "dx")
+    want_table = torch.cat([t.grad for t in tabs]).numpy()
+    assert_close(enc.table.grad.cpu().numpy(), want_table, REL_TOL, "table gradient of the same pass")
+    # coordinates only (frozen table, e.g. spatial derivatives of a trained image)
+    enc.table.requires_grad_(False)
+    xg2 = cuda(fx["x"]).requires_grad_(True)
+    enc(xg2).backward(d_out.cuda())
+    assert torch.equal(xg2.grad, xg.grad)
+
+
 # ------------------------------------------------------- lookup and decoder running side by side
 @pytest.mark.parametrize("dim,n", [(3, 1 << 18), (3, 100001), (3, 5000), (3, 33), (4, 70000), (2, 40000)])
 def test_overlapped_lookup_and_decoder_equal_the_sequential_step(amd, dim, n):
