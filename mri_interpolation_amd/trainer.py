@@ -186,7 +186,10 @@ class FusedStep:
         if ws is None:
             dev = self.flat.param.device
             new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
-            ws = dict(y=[new(n, l.weight.shape[0]) for l in self.layers])
+            # the chain kernels keep hidden activations on chip: inference needs the output only
+            skip_hidden = self.use_chain and not train
+            ws = dict(y=[None if skip_hidden and i < len(self.layers) - 1
+                         else new(n, l.weight.shape[0]) for i, l in enumerate(self.layers)])
             if self.encoder is not None:
                 ws["enc"] = new(self.encoder.output_dim, n)
             if train:

@@ -58,3 +58,42 @@ def test_two_rank_fit_on_unequal_slabs(tmp_path):
         assert r["fused"] == (kind != "batchnorm"), (kind, r)
     assert report["hash"]["optimizer_steps"] == 4      # 2 epochs x 4 batches, 2 batches per step
     assert report["siren"]["optimizer_steps"] == 8
+
+
+@pytest.mark.parametrize("dp_mode", ["all_reduce", "reduce_scatter"])
+def test_bench_two_ranks_contract(tmp_path, dp_mode):
+    """The driver's N > 1 launch of bench.py (one rank per GPU, RANK / WORLD_SIZE / MASTER_* from the
+    environment), rehearsed with two ranks on the one GPU: ONE JSON line from rank 0 with the
+    whole-job rate, weak scaling, and the `collectives` record a first real multi-GPU run needs."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: children may not be started")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MRI_DIST_BACKEND="gloo",
+                   MRI_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+             "--warmup", "2", "--workload", "cfg2", "--psnr-steps", "0", "--dp-mode", dp_mode],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("bench.py --gpus 2 did not finish")
+        outs.append(out)
+    assert [p.returncode for p in procs] == [0, 0], "\n".join(outs)
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1].splitlines())
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 6
+    assert r["config"]["global_batch"] == 2 * (1 << 18) and dp_mode in r["config"]["parallelism"]
+    assert abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    c = r["collectives"]
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["exposed_ms_per_step"] >= 0.0
+    assert "all_reduce" in r["phases_ms"] and "cpu_baseline" not in r
