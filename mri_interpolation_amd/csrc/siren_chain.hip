@@ -233,7 +233,7 @@ __global__ __launch_bounds__(G::threads, 2) void siren_forward_kernel(const Chai
       const float bias = sm.bias[0][col];
       float* __restrict__ ga = STORE ? a.act[0] : nullptr;
       float* __restrict__ gd = STORE ? a.deriv[0] : nullptr;
-#pragma unroll 4
+#pragma unroll 8  // 8 independent sincos chains in flight: the phase is latency bound at 4
       for (int r = 0; r < 32; r += 2) {
         float z0 = 0.f, z1 = 0.f;
 #pragma unroll
