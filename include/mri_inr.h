@@ -263,8 +263,8 @@ int mri_tiny_mlp_train_overlapped(const float* x, const float* target, int64_t n
  * SirenNet.forward (reference models.py:230-233): n_sine_layers x [F.linear -> sin(w0 .)]
  * (SirenLayer.forward, models.py:153-156; the first layer with w0_first) and the linear head,
  * in ONE persistent kernel: a 64-row tile's activations stay in LDS across all layers, the
- * 256 x 256 weights stream from L2 (csrc/siren_chain.hip).  Supported: hidden == 256,
- * dim_in <= 8, 1 <= n_sine_layers <= MRI_SIREN_MAX_LAYERS, one output, biases everywhere
+ * hidden x hidden weights stream from L2 (csrc/siren_chain.hip).  Supported: hidden in
+ * {32, 64, 128, 256}, dim_in <= 8, 1 <= n_sine_layers <= MRI_SIREN_MAX_LAYERS, one output, biases everywhere
  * (mri_siren_supported); other shapes go layer by layer through mri_linear_*.
  * weight / bias: HOST arrays of n_sine_layers + 1 device pointers -- [0] (hidden, dim_in),
  * [1 .. n-1] (hidden, hidden), [n] the head (1, hidden); all row-major, 16-byte aligned.
@@ -279,13 +279,13 @@ int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int32_t hidden,
                       float* const* deriv, float* y, void* stream);
 
 /* Backward of the same network (autograd of models.py:230-233 + the loss gradient dy the caller
- * got from mri_mse_loss): dz walks the layers inside LDS (one persistent kernel), each 256 x 256
- * weight gradient is one persistent kernel that keeps the whole 256 x 256 result in MFMA
+ * got from mri_mse_loss): dz walks the layers inside LDS (one persistent kernel), each hidden x hidden
+ * weight gradient is one persistent kernel that keeps the whole result in MFMA
  * accumulators; partial sums meet in `workspace` and are added in a fixed order (bitwise
  * reproducible).  act / deriv: what mri_siren_forward stored; dz: HOST array of n_sine_layers
  * device pointers to (n, hidden) scratch ([0] unused, may be NULL); d_weight / d_bias: HOST arrays
  * of n_sine_layers + 1 device pointers, gradients are ADDED to them. */
-int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t n_sine_layers);
+int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t hidden, int32_t n_sine_layers);
 int mri_siren_backward(const float* x, const float* dy, int64_t n, int32_t dim_in, int32_t hidden,
                        int32_t n_sine_layers, const float* const* weight,
                        const float* const* act, const float* const* deriv, float* const* dz,

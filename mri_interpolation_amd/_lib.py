@@ -79,7 +79,7 @@ SIGNATURES = {
 STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
                  "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64],
-                 "mri_siren_backward_workspace_bytes": [_I64, _I32],
+                 "mri_siren_backward_workspace_bytes": [_I64, _I32, _I32],
                  "mri_hashgrid_forward_signal_blocks": [C.POINTER(GridDesc), _I64],
                  "mri_tiny_mlp_round_rows": [_I32, _I32, _I64]}
 INT_GETTERS = {"mri_tiny_mlp_supported": [_I32, _I32, _I32],

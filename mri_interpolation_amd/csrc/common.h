@@ -45,7 +45,6 @@ struct Options {
   int bwd_fuse_dense = 1;         // dense levels share the launch of the record accumulation (fills its last round)
   int bwd_dense_blocks = 96;      // workgroups of the dense-level launch (all dense levels together)
   int bwd_dense_max_parts = 4;    // levels with at most this many table slices skip the records (measured optimum)
-  int siren_two_per_cu = 0;       // SIREN chain kernels: two 256-thread workgroups per CU on 32-row tiles
 };
 Options& options();
 

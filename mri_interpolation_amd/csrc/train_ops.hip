@@ -199,8 +199,6 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
     options().fwd_pair = value != 0;
   } else if (!strcmp(name, "mlp_stagger")) {
     options().mlp_stagger = value;
-  } else if (!strcmp(name, "siren_two_per_cu")) {
-    options().siren_two_per_cu = value != 0;
   } else if (!strcmp(name, "bwd_blocks_per_level")) {
     options().bwd_blocks_per_level = value < 1 ? 1 : value;
   } else {

@@ -540,7 +540,7 @@ def siren_backward(x, dy, weights, act, deriv, dz, d_weights, d_biases):
     if not (len(act) == len(deriv) == len(dz) == n_sine and
             len(d_weights) == len(d_biases) == n_sine + 1):
         raise ValueError("siren_backward: one act / deriv / dz per sine layer, one gradient per layer")
-    need = _lib.load().mri_siren_backward_workspace_bytes(n, n_sine)
+    need = _lib.load().mri_siren_backward_workspace_bytes(n, hidden, n_sine)
     ws = _siren_workspace.get(x.device.index)
     if ws is None or ws.numel() * 4 < need:
         if ws is not None:

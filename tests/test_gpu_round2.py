@@ -304,6 +304,7 @@ def test_overlapped_decoder_gives_up_instead_of_hanging(amd):
 
 # --------------------------------------------------------------------- fused SIREN chain kernels
 def _load_siren(amd, m):
+    """SirenNet with the oracle's deterministic parameters (omlp.siren_init)."""
     net = amd.models.SirenNet(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], lr=m.get("lr", 1e-4))
     with torch.no_grad():
         for layer, (w, b) in zip(list(net.layers) + [net.last_layer],
@@ -353,15 +354,18 @@ def test_siren_chain_e2e_adam_golden(amd):
             assert_close(layer.bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], 1e-4, f"b{i} step {s}")
 
 
-@pytest.mark.parametrize("dim_in,n_layers", [(3, 5), (2, 2), (4, 1), (1, 8)])
+@pytest.mark.parametrize("hidden,dim_in,n_layers", [(256, 3, 5), (256, 2, 2), (256, 4, 1), (256, 1, 8),
+                                                    (128, 3, 6), (128, 2, 1), (64, 3, 4), (64, 8, 2),
+                                                    (32, 2, 3), (32, 3, 1)])
 @pytest.mark.parametrize("n", [1, 63, 65, 1000, 33000])
-def test_siren_chain_matches_oracle_and_layerwise(amd, dim_in, n_layers, n):
-    """Ragged batches (tiles of 64 rows, chunks of 32), 1 .. 8 sine layers, 1-4 input
-    coordinates: predictions, loss and every gradient of the chain kernels against the oracle,
-    and against the layer-wise GEMM path of the same library (use_chain = False)."""
-    m = dict(dim_in=dim_in, dim_hidden=256, n_layers=n_layers, seed=100 + n_layers)
+def test_siren_chain_matches_oracle_and_layerwise(amd, hidden, dim_in, n_layers, n):
+    """Every hidden width the chain kernels serve (32 / 64 / 128 / 256: tiles of 256 / 256 / 128 / 64
+    rows), ragged batches, 1 .. 8 sine layers, 1-8 input coordinates: predictions, loss and every
+    gradient of the chain kernels against the oracle, and against the layer-wise GEMM path of the
+    same library (use_chain = False)."""
+    m = dict(dim_in=dim_in, dim_hidden=hidden, n_layers=n_layers, seed=100 + n_layers + hidden)
     net = _load_siren(amd, m)
-    model = otrain.SirenModel(dim_in, 256, 1, n_layers, seed=m["seed"])
+    model = otrain.SirenModel(dim_in, hidden, 1, n_layers, seed=m["seed"])
     x = torch.from_numpy(detrand.uniform(n * dim_in, n + 1, -1.0, 1.0).reshape(n, dim_in))
     y = torch.from_numpy(detrand.uniform(n, n + 2, -1.0, 1.0).reshape(n, 1))
     want_loss, want_pred, grads = otrain.loss_and_grads(model, x, y)
@@ -387,9 +391,39 @@ def test_siren_chain_matches_oracle_and_layerwise(amd, dim_in, n_layers, n):
     assert_close(steps[0].flat.grad.cpu().numpy(), 2 * g1.cpu().numpy(), 1e-6, "accumulated")
 
 
-def test_siren_chain_is_bitwise_reproducible(amd):
+def test_siren_chain_runs_the_reference_goldens(amd):
+    """The round-1 SIREN goldens whose widths the chain serves now go through it: `e2e_siren_adam`
+    (2 -> 32 x 3 -> 1, three Adam steps) and `siren_2d_3x64` (forward, loss, gradients)."""
+    fx = load_golden("e2e_siren_adam")
+    m = fx.meta
+    net = _load_siren(amd, m)
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    assert step.use_chain
+    layers = list(net.layers) + [net.last_layer]
+    for s in range(m["steps"]):
+        loss = float(step.train_step(cuda(fx[f"x_{s}"]), cuda(fx[f"y_{s}"])))
+        assert abs(loss - float(fx[f"loss_{s}"])) <= REL_TOL * abs(float(fx[f"loss_{s}"]))
+        for i, layer in enumerate(layers):
+            assert_close(layer.weight.detach().cpu().numpy(), fx[f"w_{s}_{i}"], REL_TOL, f"w{i} step {s}")
+            assert_close(layer.bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], REL_TOL, f"b{i} step {s}")
+    fx = load_golden("siren_2d_3x64")
+    net = _load_siren(amd, fx.meta)
+    step = amd.trainer.FusedStep(net, net.configure_optimizers())
+    assert step.use_chain
+    pred, ws = step.forward(cuda(fx["x"]), train=True)
+    assert_close(pred.cpu().numpy(), fx["pred"], REL_TOL, "pred")
+    step.backward(cuda(fx["x"]), cuda(fx["y"]), ws)
+    assert abs(float(step.loss) - float(fx["loss"])) <= REL_TOL * abs(float(fx["loss"]))
+    for i, layer in enumerate(list(net.layers) + [net.last_layer]):
+        assert_close(layer.bias.grad.cpu().numpy(), fx[f"gb_{i}"], REL_TOL, f"gb{i}")
+        head = fx[f"gw_head_{i}"]
+        assert_close(layer.weight.grad.cpu().numpy()[:head.shape[0]], head, REL_TOL, f"gw{i}")
+
+
+@pytest.mark.parametrize("hidden", [256, 64])
+def test_siren_chain_is_bitwise_reproducible(amd, hidden):
     """No float atomics: slabs summed in a fixed order -> same bits on every run."""
-    net = _load_siren(amd, dict(dim_in=3, dim_hidden=256, n_layers=5, seed=7))
+    net = _load_siren(amd, dict(dim_in=3, dim_hidden=hidden, n_layers=5, seed=7))
     step = amd.trainer.FusedStep(net, net.configure_optimizers())
     x = torch.rand(70001, 3, device="cuda") * 2 - 1
     y = torch.rand(70001, 1, device="cuda")
@@ -404,12 +438,13 @@ def test_siren_chain_is_bitwise_reproducible(amd):
 
 def test_siren_chain_rejects_unsupported_shapes(amd):
     ops = amd.ops
-    assert ops.siren_supported(3, 256, 5, 1) and not ops.siren_supported(3, 128, 5, 1)
+    assert all(ops.siren_supported(3, h, 5, 1) for h in (32, 64, 128, 256))
+    assert not ops.siren_supported(3, 96, 5, 1) and not ops.siren_supported(3, 352, 4, 1)
     assert not ops.siren_supported(9, 256, 5, 1) and not ops.siren_supported(3, 256, 9, 1)
-    net = amd.models.SirenNet(3, 64, 1, 3).cuda()           # other widths: layer by layer
+    net = amd.models.SirenNet(2, 352, 1, 4).cuda()          # the notebook's width: layer by layer
     assert not amd.trainer.FusedStep(net, net.configure_optimizers()).use_chain
-    ws = [torch.zeros(128, 3, device="cuda"), torch.zeros(1, 128, device="cuda")]
-    bs = [torch.zeros(128, device="cuda"), torch.zeros(1, device="cuda")]
+    ws = [torch.zeros(96, 3, device="cuda"), torch.zeros(1, 96, device="cuda")]
+    bs = [torch.zeros(96, device="cuda"), torch.zeros(1, device="cuda")]
     with pytest.raises(RuntimeError, match="not supported"):
         ops.siren_forward(torch.zeros(4, 3, device="cuda"), ws, bs, 30.0, 30.0)
 

@@ -29,8 +29,8 @@ def timed(fn, reps=5):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def pair(dim_in, n_layers):
-    net = models.SirenNet(dim_in, 256, 1, n_layers).cuda()
+def pair(dim_in, n_layers, hidden=256):
+    net = models.SirenNet(dim_in, hidden, 1, n_layers).cuda()
     nets = [net, copy.deepcopy(net)]
     steps = [trainer.FusedStep(m, m.configure_optimizers()) for m in nets]
     assert steps[0].use_chain and steps[1].use_chain
@@ -39,8 +39,9 @@ def pair(dim_in, n_layers):
 
 
 worst = 0.0
-for dim_in, n_layers in ((3, 5), (2, 2), (4, 1), (1, 3)):
-    nets, steps = pair(dim_in, n_layers)
+for hidden, dim_in, n_layers in ((256, 3, 5), (256, 2, 2), (128, 3, 4), (128, 4, 1), (64, 2, 3), (64, 3, 6),
+                                  (32, 1, 3), (32, 3, 2)):
+    nets, steps = pair(dim_in, n_layers, hidden)
     for n in (1, 31, 64, 65, 192, 1000, 70001):
         x = torch.rand(n, dim_in, device="cuda") * 2 - 1
         y = torch.rand(n, 1, device="cuda") * 2 - 1
@@ -56,7 +57,7 @@ for dim_in, n_layers in ((3, 5), (2, 2), (4, 1), (1, 3)):
             errs[name] = rel(p0.grad, p1.grad)
         bad = {k: v for k, v in errs.items() if not v < 2e-5}
         worst = max(worst, max(errs.values()))
-        print(f"dim_in {dim_in} layers {n_layers} n {n}: max err {max(errs.values()):.2e} "
+        print(f"hidden {hidden} dim_in {dim_in} layers {n_layers} n {n}: max err {max(errs.values()):.2e} "
               f"{'ok' if not bad else 'FAIL ' + str(bad)}", flush=True)
         assert not bad
     # whole steps stay together
