@@ -728,10 +728,10 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
     for (int i = 0; i < (W::pieces + 7) / 8; ++i) {
       const int piece = wave + 8 * i;
       if (W::pieces % 8 != 0 && piece >= W::pieces) break;
-      const int e = piece * 256 + lane * 4;  // element of the chunk
-      int64_t row = c * kKc + e / H;
+      // a piece is 256 / H rows of the chunk (one row at H = 256: the row index is then wave-uniform)
+      int64_t row = c * kKc + piece * (256 / H) + (lane * 4) / H;
       if (row >= g.n) row = g.n - 1;  // stays inside the buffers; such rows are zeroed below
-      const int64_t src = row * H + e % H;
+      const int64_t src = row * H + (lane * 4) % H;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(g.dz + src),
           (__attribute__((address_space(3))) void*)(sm.z[buf] + piece * 256), 16, 0, 0);
