@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL shares device buffers between the ranks of a node through dmabuf IPC; the variable is read
+# when HIP initialises, so it is set before torch is imported (an explicit setting wins)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # exact-f32 matrix rate (no xf32 on gfx950)
@@ -109,8 +112,13 @@ def cpu_baseline(w, name):
     bounded sample of the same workload."""
     import torch
     from oracle import train as otrain
-    # the GPU box gives one GPU a 16-CPU share (os.cpu_count() reports the whole host)
-    cores = int(os.environ.get("MRI_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    # the threads this process may run on (the box gives one GPU a share of the host's cores:
+    # the affinity mask says which; os.cpu_count() reports the whole host), 16 at most
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cores = int(os.environ.get("MRI_CPU_THREADS", max(1, min(allowed, os.cpu_count() or 1, 16))))
     torch.set_num_threads(cores)
     b = 1 << 15 if w["model"] == "hash" else 1 << 14
     dim = len(w["shape"])

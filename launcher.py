@@ -19,6 +19,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# read when HIP initialises (RCCL's dmabuf IPC between the ranks of a node): set before torch loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def parse_args(argv=None):

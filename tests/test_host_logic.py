@@ -246,3 +246,22 @@ def test_trainer_rejects_unknown_arguments_and_missing_group(monkeypatch):
     with pytest.raises(RuntimeError, match="no process group"):
         trainer.Trainer()                        # would pre-divide gradients by 4 and never reduce
     assert trainer.Trainer(distributed=False).world == 1
+
+
+def test_entry_points_set_the_ipc_mode_before_torch_loads():
+    """HSA_ENABLE_IPC_MODE_LEGACY is read when HIP initialises: bench.py and launcher.py (the
+    programs torchrun starts, one per GPU) must default it before anything imports torch."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("bench.py", "launcher.py"):
+        tree = ast.parse(open(os.path.join(root, name)).read())
+        seen_env = False
+        for node in tree.body:  # module level, in order
+            src = ast.unparse(node)
+            if "HSA_ENABLE_IPC_MODE_LEGACY" in src:
+                seen_env = True
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                mods = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+                assert seen_env or not any(m.split(".")[0] in ("torch", "mri_interpolation_amd")
+                                           for m in mods), f"{name}: torch imported before the default"
+        assert seen_env, name
