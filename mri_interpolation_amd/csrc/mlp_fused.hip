@@ -82,7 +82,8 @@ __device__ __forceinline__ void wait_slice(const FusedArgs& a, int64_t slice) {
 #ifdef MRI_MLP_PROFILE
 __device__ long long* g_mlp_profile = nullptr;
 constexpr int kProfSlots = 32;
-#define PROF_BEGIN long long p_t = clock64(); long long p_acc[kProfSlots] = {};
+#define PROF_KERNEL_START const long long p_t0 = clock64();
+#define PROF_BEGIN long long p_t = clock64(); long long p_acc[kProfSlots] = {}; p_acc[20] = p_t - p_t0;
 #define PROF_MARK(i) { const long long p_n = clock64(); p_acc[i] += p_n - p_t; p_t = p_n; }
 #define PROF_SYNC(i) { PROF_MARK(2 * (i)) __syncthreads(); PROF_MARK(2 * (i) + 1) }
 #define PROF_END(wave_in_wg)                                                              \
@@ -91,6 +92,7 @@ constexpr int kProfSlots = 32;
     for (int q = 0; q < kProfSlots; ++q) dst[q] = p_acc[q];                               \
   }
 #else
+#define PROF_KERNEL_START
 #define PROF_BEGIN
 #define PROF_MARK(i)
 #define PROF_SYNC(i) __syncthreads();
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   static_assert(H == 128 && KP == 32, "team kernel is laid out for 32 -> 128 -> 128 -> 1");
   using S = TeamSmem<H, KP>;
   __shared__ S sm;
+  PROF_KERNEL_START
   // wave-uniform indices live in SGPRs (readfirstlane), so the addresses built from them do not
   // each take a vector register for the whole kernel
   const int team = __builtin_amdgcn_readfirstlane(threadIdx.x / kTeamThreads);
@@ -817,7 +820,6 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
   }
   if (!TRAIN) return;
   PROF_MARK(18)
-  PROF_END(threadIdx.x >> 6)
   flush_dx(lane);
   if (team == 0)
     for (int q = 0; q < a.stagger; ++q) __syncthreads();
@@ -847,7 +849,11 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     (team == 0 ? red : red1)[3 * kTeamThreads + kTeamTile + tid] = loss;
   }
   __syncthreads();
-  if (team != 0) return;
+  if (team != 0) {
+    PROF_MARK(21)
+    PROF_END(threadIdx.x >> 6)
+    return;
+  }
   float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
   float* p_w1 = slab;
   float* p_b1 = p_w1 + H * a.k_in;
@@ -889,6 +895,8 @@ __global__ __launch_bounds__(2 * kTeamThreads) void tiny_mlp_team_kernel(const F
     p_b3[0] = sb;
     p_b3[1] = sl * a.inv_n;
   }
+  PROF_MARK(21)  // epilogue: team merge + slab
+  PROF_END(threadIdx.x >> 6)
 }
 
 // Sum the per-workgroup slabs in a fixed order into the gradient tensors (accumulating).

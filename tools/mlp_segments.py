@@ -81,6 +81,9 @@ def main():
             seg = names[(i - 1) % 9]
             print(f"   {seg:12s} work {float(q[2 * i]):7.0f}   wait at S{i} {float(q[2 * i + 1]):7.0f}")
         print(f"   {'tail':12s} work {float(q[18]):7.0f}")
+        pro, epi = float(q[20] * tiles), float(q[21] * tiles)
+        print(f"   once per launch: prologue (weights -> LDS, first x tile) {pro:8.0f} cycles, "
+              f"epilogue (team merge, slab) {epi:8.0f} cycles; loop {tot * tiles:9.0f}")
 
 
 if __name__ == "__main__":
