@@ -284,13 +284,30 @@ int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int32_t hidden,
  * accumulators; partial sums meet in `workspace` and are added in a fixed order (bitwise
  * reproducible).  act / deriv: what mri_siren_forward stored; dz: HOST array of n_sine_layers
  * device pointers to (n, hidden) scratch ([0] unused, may be NULL); d_weight / d_bias: HOST arrays
- * of n_sine_layers + 1 device pointers, gradients are ADDED to them. */
+ * of n_sine_layers + 1 device pointers, gradients are ADDED to them.  head_done = 1: the head's
+ * backward was done by mri_siren_forward_loss (dy, act / deriv [n_sine_layers - 1] unused). */
 int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t hidden, int32_t n_sine_layers);
 int mri_siren_backward(const float* x, const float* dy, int64_t n, int32_t dim_in, int32_t hidden,
                        int32_t n_sine_layers, const float* const* weight,
                        const float* const* act, const float* const* deriv, float* const* dz,
-                       float* const* d_weight, float* const* d_bias, void* workspace,
-                       int64_t workspace_bytes, void* stream);
+                       float* const* d_weight, float* const* d_bias, int32_t head_done,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+/* Training forward WITH the loss (models.py:61-66 training_step: y_pred = forward(x);
+ * F.mse_loss(y, y_pred)): the kernel of mri_siren_forward also compares its predictions with
+ * `target`, and runs the head's backward in the tile's tail, where the last sine layer's output
+ * and derivative are still in registers (they are NOT written to act / deriv [n_sine_layers - 1],
+ * which may be NULL): dz_last (n, hidden) = dLoss / d(pre-activation of the last sine layer), and,
+ * ADDED to them, d_w_head (1, hidden), d_b_head (1), d_b_last (hidden), loss_out[0] += mean over
+ * n_total (n <= n_total: a slice of a batch).  Gradients are scaled by 1 / grad_divisor.  Follow
+ * with mri_siren_backward(..., head_done = 1, dy = NULL), which then starts from dz_last =
+ * dz[n_sine_layers - 1].  Needs n_sine_layers >= 2; workspace: mri_siren_backward_workspace_bytes. */
+int mri_siren_forward_loss(const float* x, const float* target, int64_t n, int64_t n_total,
+                           int32_t dim_in, int32_t hidden, int32_t n_sine_layers,
+                           const float* const* weight, const float* const* bias, float w0_first,
+                           float w0, float grad_divisor, float* const* act, float* const* deriv,
+                           float* dz_last, float* y, float* d_w_head, float* d_b_head,
+                           float* d_b_last, float* loss_out, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* ---- loss ------------------------------------------------------------------------------
  * F.mse_loss(y, y_pred) (reference models.py:64): loss_out[0] += mean((pred-target)^2)

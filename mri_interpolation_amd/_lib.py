@@ -71,7 +71,11 @@ SIGNATURES = {
     "mri_siren_forward": [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_P), _F, _F,
                           C.POINTER(_P), C.POINTER(_P), _P, _P],
     "mri_siren_backward": [_P, _P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_P),
-                           C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _I64, _P],
+                           C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I32, _P, _I64,
+                           _P],
+    "mri_siren_forward_loss": [_P, _P, _I64, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_P), _F,
+                               _F, _F, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P,
+                               _I64, _P],
     "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
     "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],

@@ -66,7 +66,16 @@ struct ChainArgs {
   float* act[kMaxSine];             // (n, H) per sine layer, or null (inference)
   float* deriv[kMaxSine];
   float* y;                         // (n)
+  // loss mode (MODE 2): the head's backward runs in the forward kernel's tail, where the last sine
+  // layer's output and derivative are still in registers
+  const float* target;              // (n)
+  float grad_scale, inv_n;          // 2 / (n_total divisor), 1 / n_total
+  float* dz_last;                   // (n, H): dLoss / d(pre-activation of the last sine layer)
+  float* partial;                   // [gridDim.x][fwd_slab_floats]
 };
+
+// loss-mode slab: dW_head [H] | db_last [H] | db_head, loss (padded to 4)
+__host__ __device__ inline int fwd_slab_floats(int hidden) { return 2 * hidden + 4; }
 
 template <class S>
 struct FwdSmem {
@@ -75,6 +84,7 @@ struct FwdSmem {
   float xs[S::rows * kMaxIn];
   float bias[kMaxSine][S::H];
   float w_last[S::H];
+  float tgt[S::rows];               // loss mode: the tile's targets, then dLoss / dy
 };
 
 // row of register r of a 32x32 accumulator: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -150,10 +160,16 @@ __device__ long long* g_siren_profile = nullptr;
 #define SP_END
 #endif
 
-template <bool STORE, class S>
+// MODE 0: inference (nothing but y is written); 1: training (every layer's activation and
+// derivative leave for HBM); 2: training with the loss: MSE against `target`, and the head's
+// backward (dz of the last sine layer, dW_head, db_head, that layer's bias gradient) in the tile's
+// tail, where a and w0 cos of the last sine layer are still in registers -- they never reach HBM,
+// and the backward kernel starts from dz instead of reloading both.  Needs >= 2 sine layers.
+template <int MODE, class S>
 __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs a) {
   __shared__ FwdSmem<S> sm;
   constexpr int H = S::H, NT = S::NT;
+  constexpr bool STORE = MODE >= 1, LOSS = MODE == 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -183,6 +199,9 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
   float pa[NT][16], pd[NT][16];
   int pend_l = -1;
   int64_t pend_m0 = 0;
+  float g_wh[NT], g_bl[NT], g_bhead = 0.f, g_loss = 0.f;  // loss mode: running sums of the workgroup
+#pragma unroll
+  for (int t = 0; t < NT; ++t) g_wh[t] = g_bl[t] = 0.f;
   // lane's element offset inside a tile's (rows, H) block for accumulator register 0 of tile 0
   const int lane_off = (rb * 32 + 4 * lh) * H + n0;
   auto drip = [&](int r_lo, int r_hi, bool tile_full) {
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
       const int row = e / kMaxIn, d = e % kMaxIn;
       sm.xs[e] = (d < a.dim_in && m0 + row < a.n) ? a.x[(m0 + row) * a.dim_in + d] : 0.f;
     }
+    if (LOSS && tid < S::rows) sm.tgt[tid] = m0 + tid < a.n ? a.target[m0 + tid] : 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SP_MARK(0)  // tile top: x tile
@@ -307,8 +327,8 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
           sm.img[(rb * 32 + acc_row(r, lh)) * S::ld + n0 + t * 32] = pa[t][r];
       if (STORE) {
         pend_l = l, pend_m0 = m0;
-        if (l == n_mm) {  // no next MFMA layer in this tile: leave now
-          drip(0, 16, full_tile);
+        if (l == n_mm) {  // no next MFMA layer in this tile: leave now (loss mode: stay on chip)
+          if (!LOSS) drip(0, 16, full_tile);
           pend_l = -1;
         }
       }
@@ -331,12 +351,79 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
           if (lane + 64 * j < H) acc1 += sm.img[row * S::ld + lane + 64 * j] * wv[j];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc1 += __shfl_down(acc1, off, 64);
-        if (lane == 0 && m0 + row < a.n) a.y[m0 + row] = acc1 + b_last;
+        if (lane == 0 && m0 + row < a.n) {
+          const float yv = acc1 + b_last;
+          a.y[m0 + row] = yv;
+          if (LOSS) {  // models.py:64 F.mse_loss: mean((y - target)^2); dLoss/dy = 2 (y - t) / N
+            const float diff = yv - sm.tgt[row];
+            g_loss += diff * diff;
+            const float dyv = diff * a.grad_scale;
+            g_bhead += dyv;
+            sm.tgt[row] = dyv;
+          }
+        } else if (LOSS && lane == 0) {
+          sm.tgt[row] = 0.f;
+        }
+      }
+    }
+    if (LOSS) {
+      // ---- head backward: dz = dy w_head (.) w0 cos, dW_head += dy^T a, db_last += colsum(dz) -----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every row's dLoss/dy is in LDS
+      float* __restrict__ gz = a.dz_last + m0 * H;
+      int off = lane_off;
+      asm volatile("" : "+v"(off));
+      const int64_t rows_left = a.n - m0 - rb * 32 - 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float wl = sm.w_last[n0 + 32 * t];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const float dyv = sm.tgt[rb * 32 + 4 * lh + dr];
+          g_wh[t] += dyv * pa[t][r];
+          const float dz = (dyv * wl) * pd[t][r];
+          g_bl[t] += dz;
+          if (full_tile || dr < rows_left) gz[off + dr * H + t * 32] = dz;
+        }
       }
     }
     SP_MARK(7)  // head
   }
   SP_END
+  if (LOSS) {
+    // ---- this workgroup's slab: dW_head, db of the last sine layer, db_head, loss -----------------
+    float* slab = a.partial + (int64_t)blockIdx.x * fwd_slab_floats(H);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = sm.img;  // scratch: [row block][H] per quantity
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float wh = g_wh[t] + __shfl_xor(g_wh[t], 32, 64);  // the lane halves hold different rows
+      const float bl = g_bl[t] + __shfl_xor(g_bl[t], 32, 64);
+      if (lh == 0) {
+        red[rb * H + n0 + 32 * t] = wh;
+        red[(S::RB + rb) * H + n0 + 32 * t] = bl;
+      }
+    }
+    __syncthreads();
+    if (tid < H) {
+      float wh = 0.f, bl = 0.f;
+#pragma unroll
+      for (int q = 0; q < S::RB; ++q) wh += red[q * H + tid], bl += red[(S::RB + q) * H + tid];
+      slab[tid] = wh;
+      slab[H + tid] = bl;
+    }
+    __syncthreads();
+    red[tid] = lane == 0 ? g_bhead : 0.f;  // lane 0 of each wave holds its rows' sums
+    red[kThreads + tid] = lane == 0 ? g_loss : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+      float sb = 0.f, sl = 0.f;
+      for (int w = 0; w < 8; ++w) sb += red[w * 64], sl += red[kThreads + w * 64];
+      slab[2 * H] = sb, slab[2 * H + 1] = sl * a.inv_n, slab[2 * H + 2] = 0.f, slab[2 * H + 3] = 0.f;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,6 +449,7 @@ struct BwdArgs {
   const float* deriv[kMaxSine];    // (n, H) per sine layer: w0 cos(.)
   float* dz[kMaxSine];             // (n, H) for sine layers 1 .. n_sine-1 ([0] unused)
   float* partial;                  // [gridDim.x][bwd_slab_floats]
+  int head_done;                   // dz[n_sine-1] is an INPUT (the forward kernel's loss mode wrote it)
 };
 
 // slab: dW_head [H] | db_head [1] (padded to 4) | db_l [n_sine][H] | dW_first [H][kMaxIn]
@@ -493,13 +581,23 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
       const int row = e / kMaxIn, d = e % kMaxIn;
       sm.xs[e] = (d < a.dim_in && m0 + row < a.n) ? a.x[(m0 + row) * a.dim_in + d] : 0.f;
     }
-    if (tid < S::rows) {
+    if (!a.head_done && tid < S::rows) {
       const float v = m0 + tid < a.n ? a.dy[m0 + tid] : 0.f;
       sm.dy[tid] = v;
       g_bhead += v;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (a.head_done) {
+      // ---- the forward kernel's tail did the head: the image starts as dz_{L-1} ------------------
+      const float* __restrict__ gz = a.dz[L - 1] + m0 * H + col;
+      float zv[S::rpt];  // every load in flight before the first LDS store
+#pragma unroll
+      for (int i = 0; i < S::rpt; ++i)
+        zv[i] = (full_tile || m0 + r0 + i < a.n) ? gz[(r0 + i) * H] : 0.f;
+#pragma unroll
+      for (int i = 0; i < S::rpt; ++i) sm.img[(r0 + i) * S::ld + col] = zv[i];
+    } else
     // ---- head: dz_{L-1} = dy w_head (.) d_{L-1}; dW_head += dy^T a_{L-1} ------------------------
     {
       const float wl = sm.w_last[col];
@@ -820,13 +918,15 @@ int chain_blocks(int hidden, int64_t n) { return (int)std::min<int64_t>(ceil_div
 int wgrad_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kKc), 256); }
 
 template <int H>
-int launch_forward(const ChainArgs& a, bool store, hipStream_t st) {
+int launch_forward(const ChainArgs& a, int mode, hipStream_t st) {
   using S = Shape<H>;
   const int blocks = chain_blocks(H, a.n);  // one workgroup per CU
-  if (store)
-    hipLaunchKernelGGL((siren_forward_kernel<true, S>), dim3(blocks), dim3(kThreads), 0, st, a);
+  if (mode == 2)
+    hipLaunchKernelGGL((siren_forward_kernel<2, S>), dim3(blocks), dim3(kThreads), 0, st, a);
+  else if (mode == 1)
+    hipLaunchKernelGGL((siren_forward_kernel<1, S>), dim3(blocks), dim3(kThreads), 0, st, a);
   else
-    hipLaunchKernelGGL((siren_forward_kernel<false, S>), dim3(blocks), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL((siren_forward_kernel<0, S>), dim3(blocks), dim3(kThreads), 0, st, a);
   return check_launch("siren_forward_kernel");
 }
 
@@ -847,13 +947,39 @@ int launch_wgrad(const WgradArgs& g, float* d_weight, hipStream_t st) {
   return check_launch("siren_wgrad_kernel");
 }
 
-int forward_any(int hidden, const ChainArgs& a, bool store, hipStream_t st) {
+int forward_any(int hidden, const ChainArgs& a, int mode, hipStream_t st) {
   switch (hidden) {
-    case 32: return launch_forward<32>(a, store, st);
-    case 64: return launch_forward<64>(a, store, st);
-    case 128: return launch_forward<128>(a, store, st);
-    default: return launch_forward<256>(a, store, st);
+    case 32: return launch_forward<32>(a, mode, st);
+    case 64: return launch_forward<64>(a, mode, st);
+    case 128: return launch_forward<128>(a, mode, st);
+    default: return launch_forward<256>(a, mode, st);
   }
+}
+
+// loss-mode slabs -> head weight / bias gradient, last sine layer's bias gradient, loss
+struct FwdReduceArgs {
+  const float* partial;
+  int slabs, hidden;
+  float* d_w_head;
+  float* d_b_head;
+  float* d_b_last;
+  float* loss_out;
+};
+
+__global__ __launch_bounds__(256) void siren_fwd_reduce_kernel(const FwdReduceArgs r) {
+  const int H = r.hidden, slab = fwd_slab_floats(H);
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= slab) return;
+  float sum = 0.f;
+  for (int b = 0; b < r.slabs; ++b) sum += r.partial[(int64_t)b * slab + e];
+  if (e < H)
+    r.d_w_head[e] += sum;
+  else if (e < 2 * H)
+    r.d_b_last[e - H] += sum;
+  else if (e == 2 * H)
+    r.d_b_head[0] += sum;
+  else if (e == 2 * H + 1)
+    r.loss_out[0] += sum;
 }
 
 int backward_any(int hidden, const BwdArgs& a, hipStream_t st) {
@@ -909,7 +1035,52 @@ extern "C" int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int3
       MRI_REQUIRE(act[l] && deriv[l], "NULL activation buffer (layer %d)", l);
       a.act[l] = act[l], a.deriv[l] = deriv[l];
     }
-  return forward_any(hidden, a, act != nullptr, (hipStream_t)stream);
+  return forward_any(hidden, a, act != nullptr ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64_t n,
+                                      int64_t n_total, int32_t dim_in, int32_t hidden,
+                                      int32_t n_sine_layers, const float* const* weight,
+                                      const float* const* bias, float w0_first, float w0,
+                                      float grad_divisor, float* const* act, float* const* deriv,
+                                      float* dz_last, float* y, float* d_w_head, float* d_b_head,
+                                      float* d_b_last, float* loss_out, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  MRI_REQUIRE(chain_supported(dim_in, hidden, n_sine_layers, 1) && n_sine_layers >= 2,
+              "fused SIREN chain with loss: %d -> %d x %d -> 1 is not supported (>= 2 sine layers)",
+              dim_in, hidden, n_sine_layers);
+  MRI_REQUIRE(n >= 0 && n < (1ll << 31) && n_total >= n && grad_divisor > 0.f, "bad n / divisor");
+  if (n == 0) return MRI_OK;
+  MRI_REQUIRE(x && target && weight && bias && act && deriv && dz_last && y && d_w_head &&
+                  d_b_head && d_b_last && loss_out, "NULL pointer");
+  const int blocks = chain_blocks(hidden, n);
+  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)blocks * fwd_slab_floats(hidden) * 4,
+              "SIREN forward with loss needs a workspace of %lld bytes",
+              (long long)blocks * fwd_slab_floats(hidden) * 4);
+  ChainArgs a{};
+  a.x = x, a.n = n, a.dim_in = dim_in, a.n_sine = n_sine_layers;
+  a.w0_first = w0_first, a.w0 = w0, a.y = y;
+  a.target = target, a.dz_last = dz_last, a.partial = static_cast<float*>(workspace);
+  a.grad_scale = (float)(2.0 / ((double)n_total * (double)grad_divisor));
+  a.inv_n = (float)(1.0 / (double)n_total);
+  for (int l = 0; l <= n_sine_layers; ++l) {
+    MRI_REQUIRE(weight[l] && bias[l], "NULL parameter pointer (layer %d)", l);
+    MRI_REQUIRE((reinterpret_cast<uintptr_t>(weight[l]) & 15) == 0,
+                "weights must be 16-byte aligned (layer %d)", l);
+    a.w[l] = weight[l], a.b[l] = bias[l];
+  }
+  for (int l = 0; l + 1 < n_sine_layers; ++l) {  // the last sine layer's a / w0 cos stay on chip
+    MRI_REQUIRE(act[l] && deriv[l], "NULL activation buffer (layer %d)", l);
+    a.act[l] = act[l], a.deriv[l] = deriv[l];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = forward_any(hidden, a, 2, st)) return rc;
+  FwdReduceArgs r{};
+  r.partial = a.partial, r.slabs = blocks, r.hidden = hidden;
+  r.d_w_head = d_w_head, r.d_b_head = d_b_head, r.d_b_last = d_b_last, r.loss_out = loss_out;
+  hipLaunchKernelGGL(siren_fwd_reduce_kernel, dim3((unsigned)ceil_div(fwd_slab_floats(hidden), 256)),
+                     dim3(256), 0, st, r);
+  return check_launch("siren_fwd_reduce_kernel");
 }
 
 extern "C" int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t hidden,
@@ -925,14 +1096,17 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
                                   int32_t hidden, int32_t n_sine_layers,
                                   const float* const* weight, const float* const* act,
                                   const float* const* deriv, float* const* dz,
-                                  float* const* d_weight, float* const* d_bias, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+                                  float* const* d_weight, float* const* d_bias,
+                                  int32_t head_done, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
   MRI_REQUIRE(chain_supported(dim_in, hidden, n_sine_layers, 1),
               "fused SIREN chain: %d -> %d x %d -> 1 is not supported", dim_in, hidden,
               n_sine_layers);
+  MRI_REQUIRE(!head_done || n_sine_layers >= 2, "head_done needs >= 2 sine layers");
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   if (n == 0) return MRI_OK;
-  MRI_REQUIRE(x && dy && weight && act && deriv && dz && d_weight && d_bias, "NULL pointer");
+  MRI_REQUIRE(x && (dy || head_done) && weight && act && deriv && dz && d_weight && d_bias,
+              "NULL pointer");
   const int L = n_sine_layers;
   const int64_t need = mri_siren_backward_workspace_bytes(n, hidden, L);
   MRI_REQUIRE(workspace && workspace_bytes >= need,
@@ -948,14 +1122,17 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
     a.w[l] = weight[l];
   }
   for (int l = 0; l < L; ++l) {
-    MRI_REQUIRE(act[l] && deriv[l] && (l == 0 || dz[l]), "NULL activation buffer (layer %d)", l);
-    MRI_REQUIRE((reinterpret_cast<uintptr_t>(act[l]) & 15) == 0 &&
+    const bool on_chip = head_done && l == L - 1;  // the loss-mode forward never stored these
+    MRI_REQUIRE((on_chip || (act[l] && deriv[l])) && (l == 0 || dz[l]),
+                "NULL activation buffer (layer %d)", l);
+    MRI_REQUIRE((on_chip || (reinterpret_cast<uintptr_t>(act[l]) & 15) == 0) &&
                     (l == 0 || (reinterpret_cast<uintptr_t>(dz[l]) & 15) == 0),
                 "activation buffers must be 16-byte aligned");
-    a.deriv[l] = deriv[l];
+    a.deriv[l] = on_chip ? nullptr : deriv[l];
     a.dz[l] = dz[l];
   }
-  a.act_last = act[L - 1];
+  a.act_last = head_done ? nullptr : act[L - 1];
+  a.head_done = head_done ? 1 : 0;
   if (int rc = backward_any(hidden, a, st)) return rc;
   BwdReduceArgs r{};
   r.partial = a.partial, r.slabs = chain_blocks(hidden, n), r.hidden = hidden, r.n_sine = L;

@@ -529,28 +529,71 @@ def siren_forward(x, weights, biases, w0_first: float, w0: float, act=None, deri
 _siren_workspace = {}
 
 
-def siren_backward(x, dy, weights, act, deriv, dz, d_weights, d_biases):
+def _siren_scratch(device, n, hidden, n_sine):
+    need = _lib.load().mri_siren_backward_workspace_bytes(n, hidden, n_sine)
+    ws = _siren_workspace.get(device.index)
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            torch.cuda.synchronize(device)
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        _siren_workspace[device.index] = ws
+    return ws
+
+
+def _opt_ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def siren_forward_loss(x, target, weights, biases, w0_first: float, w0: float, act, deriv, dz_last,
+                       y, d_w_head, d_b_head, d_b_last, loss_out, grad_divisor: float = 1.0,
+                       n_total=None):
+    """Training forward of the fused SIREN chain with F.mse_loss and the head's backward in the
+    same kernel (mri_siren_forward_loss, include/mri_inr.h).  act / deriv: per sine layer
+    (n, hidden) buffers, the LAST layer's may be None (it stays on chip); dz_last (n, hidden)
+    receives the gradient w.r.t. the last sine layer's pre-activation; d_w_head, d_b_head,
+    d_b_last and loss_out are ADDED to.  Follow with siren_backward(..., head_done=True)."""
+    _gpu(x, target, y, dz_last, d_w_head, d_b_head, d_b_last, loss_out, *weights, *biases,
+         *[t for t in list(act) + list(deriv) if t is not None])
+    x = _rowmajor(x).contiguous()
+    n, dim_in = x.shape
+    n_sine, hidden = len(weights) - 1, weights[0].shape[0]
+    if len(act) != n_sine or len(deriv) != n_sine:
+        raise ValueError("act and deriv: one entry per sine layer (the last may be None)")
+    if target.numel() != n or not target.is_contiguous() or y.numel() != n or \
+            dz_last.shape != (n, hidden):
+        raise ValueError("siren_forward_loss: target / y (n, 1) contiguous, dz_last (n, hidden)")
+    for t in list(weights) + list(biases) + [t for t in list(act) + list(deriv) if t is not None] + \
+            [dz_last, y, d_w_head, d_b_head, d_b_last]:
+        if not t.is_contiguous():
+            raise ValueError("siren_forward_loss needs contiguous parameters and buffers")
+    ws = _siren_scratch(x.device, n, hidden, n_sine)
+    _lib.call("mri_siren_forward_loss", _ptr(x), _ptr(target), n, n if n_total is None else n_total,
+              dim_in, hidden, n_sine, _ptr_array(weights), _ptr_array(biases), float(w0_first),
+              float(w0), float(grad_divisor), _opt_ptr_array(act), _opt_ptr_array(deriv),
+              _ptr(dz_last), _ptr(y), _ptr(d_w_head), _ptr(d_b_head), _ptr(d_b_last), _ptr(loss_out),
+              _ptr(ws), ws.numel() * 4, _stream())
+    return y
+
+
+def siren_backward(x, dy, weights, act, deriv, dz, d_weights, d_biases, head_done: bool = False):
     """Gradients of the fused SIREN chain, ADDED to d_weights / d_biases (sine layers, then the
     head).  dy: (n, 1) loss gradient w.r.t. the prediction; act / deriv: what siren_forward
-    stored; dz: per sine layer (n, hidden) scratch (dz[0] may be None)."""
-    _gpu(x, dy, *weights, *act, *deriv, *[t for t in dz if t is not None], *d_weights, *d_biases)
+    stored; dz: per sine layer (n, hidden) scratch (dz[0] may be None).  head_done: the head's
+    backward already ran in siren_forward_loss, which left its result in dz[-1] (dy and the last
+    act / deriv are not read, and may be None)."""
+    _gpu(x, dy, *weights, *[t for t in list(act) + list(deriv) + list(dz) if t is not None],
+         *d_weights, *d_biases)
     x = _rowmajor(x).contiguous()
     n, dim_in = x.shape
     n_sine, hidden = len(weights) - 1, weights[0].shape[0]
     if not (len(act) == len(deriv) == len(dz) == n_sine and
             len(d_weights) == len(d_biases) == n_sine + 1):
         raise ValueError("siren_backward: one act / deriv / dz per sine layer, one gradient per layer")
-    need = _lib.load().mri_siren_backward_workspace_bytes(n, hidden, n_sine)
-    ws = _siren_workspace.get(x.device.index)
-    if ws is None or ws.numel() * 4 < need:
-        if ws is not None:
-            torch.cuda.synchronize(x.device)
-        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
-        _siren_workspace[x.device.index] = ws
-    dz_ptrs = (C.c_void_p * n_sine)(*[t.data_ptr() if t is not None else None for t in dz])
+    ws = _siren_scratch(x.device, n, hidden, n_sine)
     _lib.call("mri_siren_backward", _ptr(x), _ptr(dy), n, dim_in, hidden, n_sine,
-              _ptr_array(weights), _ptr_array(act), _ptr_array(deriv), dz_ptrs,
-              _ptr_array(d_weights), _ptr_array(d_biases), _ptr(ws), ws.numel() * 4, _stream())
+              _ptr_array(weights), _opt_ptr_array(act), _opt_ptr_array(deriv), _opt_ptr_array(dz),
+              _ptr_array(d_weights), _ptr_array(d_biases), 1 if head_done else 0, _ptr(ws),
+              ws.numel() * 4, _stream())
 
 
 # --------------------------------------------------------------------------- loss / optimiser

@@ -87,6 +87,9 @@ class FusedStep:
         self.use_tiny = self.tiny is not None
         self.chain = self._siren_chain_plan()
         self.use_chain = self.chain is not None
+        # train_step folds the loss and the head's backward into the forward kernel (needs a
+        # sine layer below the last one); forward() + backward() keep the separate kernels
+        self.chain_loss = self.use_chain and len(self.layers) >= 3
         # Data parallel: the table gradient is produced level by level, so its reduction is cut
         # into `grad_buckets` level groups; group g's all-reduce (RCCL, its own stream) runs
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
@@ -444,6 +447,28 @@ class FusedStep:
             with self._phase("hashgrid_bwd"):
                 self._pending = started + self._hash_backward(coords, ws["d_enc"], reduce=step)
 
+    def _chain_loss_pass(self, coords, target, first, divisor):
+        """forward + loss + backward of the SIREN chain in three launches: the forward kernel also
+        takes the loss and runs the head's backward while the last sine layer's output is still in
+        registers (it is never written), the backward kernel starts from that."""
+        ws = self._workspace(coords.shape[0], True)
+        c, n_sine = self.chain, len(self.layers) - 1
+        with self._phase("zero_grad"):
+            if first:
+                self.flat.grad.zero_()
+            self.loss.zero_()
+        act, deriv = ws["y"][:n_sine], ws["deriv"][:n_sine]
+        with self._phase("mlp_fwd"):
+            ops.siren_forward_loss(coords, target, c["weights"], c["biases"], c["w0_first"], c["w0"],
+                                   act[:-1] + [None], deriv[:-1] + [None], ws["dz"][n_sine - 1],
+                                   ws["y"][-1], c["d_weights"][-1], c["d_biases"][-1],
+                                   c["d_biases"][n_sine - 1], self.loss,
+                                   grad_divisor=float(self.world) * float(divisor))
+        with self._phase("mlp_bwd"):
+            ops.siren_backward(coords, None, c["weights"], act[:-1] + [None], deriv[:-1] + [None],
+                               [None] + ws["dz"][1:n_sine], c["d_weights"], c["d_biases"],
+                               head_done=True)
+
     def train_step(self, coords, target, side_work=None, first=True, step=True,
                    divisor=1.0) -> torch.Tensor:
         """One batch: forward, loss, backward and -- with `step` -- gradient reduction and Adam;
@@ -464,9 +489,13 @@ class FusedStep:
                 with torch.cuda.stream(self._side):
                     side_work()
                 side_work = None
-        _, ws = self.forward(coords, train=True)
-        self._pending = []
-        self.backward(coords, target, ws, first, step, divisor)
+        if self.use_chain and self.chain_loss:
+            self._pending = []
+            self._chain_loss_pass(coords, target, first, divisor)
+        else:
+            _, ws = self.forward(coords, train=True)
+            self._pending = []
+            self.backward(coords, target, ws, first, step, divisor)
         if not step:
             if side_work is not None:
                 side_work()

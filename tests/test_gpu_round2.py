@@ -420,6 +420,43 @@ def test_siren_chain_runs_the_reference_goldens(amd):
         assert_close(layer.weight.grad.cpu().numpy()[:head.shape[0]], head, REL_TOL, f"gw{i}")
 
 
+@pytest.mark.parametrize("hidden,dim_in,n_layers,n", [(256, 3, 5, 70001), (256, 2, 2, 64), (128, 3, 6, 4097),
+                                                      (64, 8, 3, 1), (32, 2, 3, 5000), (256, 3, 5, 63)])
+def test_siren_chain_loss_in_forward_matches_separate_kernels(amd, hidden, dim_in, n_layers, n):
+    """train_step's pass (loss and the head's backward inside the forward kernel, the last sine
+    layer's output never stored; FusedStep._chain_loss_pass) against forward() + backward() with
+    their separate loss / head phases, and against the oracle; accumulation and divisor too."""
+    m = dict(dim_in=dim_in, dim_hidden=hidden, n_layers=n_layers, seed=300 + n_layers + hidden)
+    net = _load_siren(amd, m)
+    model = otrain.SirenModel(dim_in, hidden, 1, n_layers, seed=m["seed"])
+    x = torch.from_numpy(detrand.uniform(n * dim_in, n + 1, -1.0, 1.0).reshape(n, dim_in))
+    y = torch.from_numpy(detrand.uniform(n, n + 2, -1.0, 1.0).reshape(n, 1))
+    want_loss, want_pred, grads = otrain.loss_and_grads(model, x, y)
+    st = amd.trainer.FusedStep(net, net.configure_optimizers())
+    assert st.use_chain and st.chain_loss
+    xc, yc = x.cuda(), y.cuda()
+    pred, ws = st.forward(xc, train=True)
+    st.backward(xc, yc, ws)
+    g_sep, loss_sep, pred_sep = st.flat.grad.clone(), float(st.loss), pred.clone()
+    st.flat.grad.fill_(float("nan"))  # first=True must start afresh
+    st._chain_loss_pass(xc, yc, True, 1.0)
+    ws = st._workspace(n, True)
+    assert torch.equal(ws["y"][-1], pred_sep)  # same forward arithmetic
+    assert abs(float(st.loss) - loss_sep) <= 1e-6 * max(abs(loss_sep), 0.1)
+    assert abs(float(st.loss) - float(want_loss)) <= REL_TOL * max(abs(float(want_loss)), 0.1)
+    for i, layer in enumerate(list(net.layers) + [net.last_layer]):
+        assert_close(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), REL_TOL, f"gw{i}")
+        assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), REL_TOL, f"gb{i}")
+    g_one = st.flat.grad.clone()
+    assert_close(g_one.cpu().numpy(), g_sep.cpu().numpy(), 2e-6, "fused loss vs separate kernels")
+    # accumulation: a second pass with first=False adds; divisor scales
+    st._chain_loss_pass(xc, yc, False, 1.0)
+    assert_close(st.flat.grad.cpu().numpy(), 2 * g_one.cpu().numpy(), 1e-6, "accumulated")
+    st._chain_loss_pass(xc, yc, True, 4.0)
+    assert_close(st.flat.grad.cpu().numpy(), g_one.cpu().numpy() / 4, 1e-6, "divisor")
+    assert abs(float(st.loss) - loss_sep) <= 1e-6 * max(abs(loss_sep), 0.1)  # the loss is not divided
+
+
 @pytest.mark.parametrize("hidden", [256, 64])
 def test_siren_chain_is_bitwise_reproducible(amd, hidden):
     """No float atomics: slabs summed in a fixed order -> same bits on every run."""

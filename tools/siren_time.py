@@ -20,3 +20,7 @@ for chain in (True, False):
     print("hidden %d %s: infer %.3f  fwd %.3f  bwd %.3f  step %.3f ms" % (hidden, "chain     " if st.use_chain else "layer-wise",
         timed(lambda: st.forward(x, train=False)), timed(lambda: st.forward(x, train=True)),
         timed(lambda: st.backward(x, y, ws)), timed(lambda: st.train_step(x, y))), flush=True)
+    if st.use_chain and st.chain_loss:
+        st.chain_loss = False
+        print("   step with separate loss / head kernels %.3f ms" % timed(lambda: st.train_step(x, y)), flush=True)
+        st.chain_loss = True
