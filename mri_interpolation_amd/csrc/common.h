@@ -42,6 +42,7 @@ struct Options {
   int bwd_blocks_per_level = 64;  // target workgroups per level of the LDS backward (hit balance)
   int fwd_pair = 1;               // F = 2 forward: two lanes per (coordinate, level), see hashgrid.hip
   int mlp_stagger = 0;            // fused tiny MLP (H = 128): segments team 1 runs behind team 0 (0 = lockstep: measured best)
+  int mlp_x3 = 1;                 // 128-wide decoder on the bf16 matrix pipe with three-term operands (mlp_x3.hip); 0: f32 MFMA team kernel
   int bwd_fuse_dense = 1;         // dense levels share the launch of the record accumulation (fills its last round)
   int bwd_dense_blocks = 96;      // workgroups of the dense-level launch (all dense levels together)
   int bwd_dense_max_parts = 4;    // levels with at most this many table slices skip the records (measured optimum)

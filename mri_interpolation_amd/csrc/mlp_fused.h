@@ -1,0 +1,41 @@
+// Shared by the fused tiny-MLP kernels (mlp_fused.hip: f32 MFMA; mlp_x3.hip: bf16x3 MFMA).
+#pragma once
+#include "common.h"
+
+namespace mri {
+
+struct FusedArgs {
+  const float* x;      // (k_in, n) feature-major
+  const float* target; // (n)
+  const float* w1; const float* b1;   // (H, k_in), (H)
+  const float* w2; const float* b2;   // (H, H), (H)
+  const float* w3; const float* b3;   // (1, H), (1)
+  float* y;            // (n) predictions, optional
+  float* dx;           // (k_in, n) feature-major, optional
+  float* partial;      // [gridDim.x][slab] partial gradients + loss
+  int64_t n;
+  int64_t ld;          // leading dimension of x and dx (elements between feature rows), >= n
+  int k_in;
+  float grad_scale;    // 2 / (n * grad_divisor)
+  int stagger;         // team kernel: segments team 1 runs behind team 0
+  float inv_n;
+  // team kernel, optional: x is being PRODUCED by a kernel running beside this one (the
+  // signalling hash-grid lookup of hashgrid.hip); slice r = the rows round r of the workgroups
+  // reads, complete when ready[r] >= ready_target
+  const unsigned long long* ready;
+  unsigned long long ready_target;
+  int* status;         // set to 1 if a wait gave up (the producer never arrived)
+};
+
+
+// slab layout (floats): dW1 [H*k_in] | db1 [H] | dW2 [H*H] | db2 [H] | dW3 [H] | db3 [1] | loss [1]
+__host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + H + H * H + H + H + 2; }
+
+// mlp_x3.hip: 32 -> 128 -> 128 -> 1 on the bf16 matrix pipe (three-term split operands), one
+// 512-thread workgroup per CU, one slab per workgroup (train).  `blocks` <= x3_max_blocks(n).
+bool x3_supported(int k_in, int hidden);
+bool x3_addressable(const FusedArgs& a);  // 32-bit lane offsets inside x / dx
+int x3_blocks(int64_t n);
+int launch_tiny_mlp_x3(const FusedArgs& a, bool train, int blocks, hipStream_t st);
+
+}  // namespace mri

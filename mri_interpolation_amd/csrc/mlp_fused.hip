@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "mlp_fused.h"
 
 namespace mri {
 namespace {
@@ -33,29 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTile = 64;       // coordinates per workgroup iteration
 constexpr int kThreads = 256;   // 4 waves
-
-struct FusedArgs {
-  const float* x;      // (k_in, n) feature-major
-  const float* target; // (n)
-  const float* w1; const float* b1;   // (H, k_in), (H)
-  const float* w2; const float* b2;   // (H, H), (H)
-  const float* w3; const float* b3;   // (1, H), (1)
-  float* y;            // (n) predictions, optional
-  float* dx;           // (k_in, n) feature-major, optional
-  float* partial;      // [gridDim.x][slab] partial gradients + loss
-  int64_t n;
-  int64_t ld;          // leading dimension of x and dx (elements between feature rows), >= n
-  int k_in;
-  float grad_scale;    // 2 / (n * grad_divisor)
-  int stagger;         // team kernel: segments team 1 runs behind team 0
-  float inv_n;
-  // team kernel, optional: x is being PRODUCED by a kernel running beside this one (the
-  // signalling hash-grid lookup of hashgrid.hip); slice r = the rows round r of the workgroups
-  // reads, complete when ready[r] >= ready_target
-  const unsigned long long* ready;
-  unsigned long long ready_target;
-  int* status;         // set to 1 if a wait gave up (the producer never arrived)
-};
 
 // Consumer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): ONE lane polls
 // with relaxed agent-scope loads, then ONE agent-scope acquire (invalidates this CU's L1) and
@@ -112,8 +90,6 @@ struct Smem {
   float ypart[4 * kTile];
 };
 
-// slab layout (floats): dW1 [H*k_in] | db1 [H] | dW2 [H*H] | db2 [H] | dW3 [H] | db3 [1] | loss [1]
-__host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + H + H * H + H + H + 2; }
 
 // acc[ti][tj] += A(i, c) * B(j, c) over `steps` pairs of contraction indices, 32x32 tiles.
 // a / b point at this lane's element of tile (0,0) for contraction index 0; consecutive tiles are
@@ -956,7 +932,12 @@ int pick_blocks(int hidden, int64_t n) {
   return (int)std::min<int64_t>(ceil_div(n, kTile), 512);  // 52-75 KiB of LDS: two per CU
 }
 
-int slab_count(int hidden, int blocks) { (void)hidden; return blocks; }  // one slab per workgroup
+// one slab per workgroup; the workspace is sized for whichever kernel the options select later
+int slab_count(int hidden, int k_in, int64_t n) {
+  int blocks = pick_blocks(hidden, n);
+  if (x3_supported(k_in, hidden)) blocks = std::max(blocks, x3_blocks(n));
+  return blocks;
+}
 
 bool supported(int k_in, int hidden, int dim_out) {
   if (dim_out != 1 || k_in < 1) return false;
@@ -965,7 +946,14 @@ bool supported(int k_in, int hidden, int dim_out) {
   return false;
 }
 
+// the bf16x3 kernel serves 128-wide decoders unless switched off (option mlp_x3) or the input is
+// being produced beside the kernel (the ready counters are the team kernel's)
+bool use_x3(const FusedArgs& a, int hidden) {
+  return options().mlp_x3 && x3_supported(a.k_in, hidden) && x3_addressable(a) && a.ready == nullptr;
+}
+
 int dispatch(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
+  if (use_x3(a, hidden)) return launch_tiny_mlp_x3(a, train, blocks, st);
   if (hidden == 128) {  // tiny_mlp_kernel<128, ...> (one 4-wave team) is not instantiated: 7 % slower
     if (train)
       hipLaunchKernelGGL((tiny_mlp_team_kernel<128, 32, true>), dim3(blocks),
@@ -990,8 +978,7 @@ extern "C" int mri_tiny_mlp_supported(int32_t k_in, int32_t hidden, int32_t dim_
 
 extern "C" int64_t mri_tiny_mlp_workspace_bytes(int32_t k_in, int32_t hidden, int64_t n) {
   if (!supported(k_in, hidden, 1)) return -1;
-  return (int64_t)slab_count(hidden, pick_blocks(hidden, std::max<int64_t>(n, 1))) *
-         slab_floats(hidden, k_in) * 4;
+  return (int64_t)slab_count(hidden, k_in, std::max<int64_t>(n, 1)) * slab_floats(hidden, k_in) * 4;
 }
 
 extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int32_t hidden,
@@ -1006,7 +993,8 @@ extern "C" int mri_tiny_mlp_forward(const float* x, int64_t n, int32_t k_in, int
   FusedArgs a{};
   a.x = x, a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3, a.y = y;
   a.n = n, a.ld = n, a.k_in = k_in;
-  return dispatch(a, hidden, false, pick_blocks(hidden, n), (hipStream_t)stream);
+  return dispatch(a, hidden, false, use_x3(a, hidden) ? x3_blocks(n) : pick_blocks(hidden, n),
+                  (hipStream_t)stream);
 }
 
 struct Overlap {
@@ -1031,12 +1019,10 @@ static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const
   if (n == 0) return MRI_OK;
   MRI_REQUIRE(x && target && w1 && b1 && w2 && b2 && w3 && b3, "NULL device pointer");
   MRI_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && loss_out, "NULL gradient pointer");
-  const int blocks = pick_blocks(hidden, n);
   const int slab = slab_floats(hidden, k_in);
-  const int slabs = slab_count(hidden, blocks);
-  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)slabs * slab * 4,
+  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)slab_count(hidden, k_in, n) * slab * 4,
               "tiny MLP needs a workspace of %lld bytes (mri_tiny_mlp_workspace_bytes)",
-              (long long)slabs * slab * 4);
+              (long long)slab_count(hidden, k_in, n) * slab * 4);
   FusedArgs a{};
   a.x = x, a.target = target;
   a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3;
@@ -1046,6 +1032,8 @@ static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const
   a.inv_n = (float)(1.0 / (double)n_total);
   a.stagger = std::min(std::max(options().mlp_stagger, 0), 8);
   a.ready = overlap.ready, a.ready_target = overlap.target, a.status = overlap.status;
+  const int blocks = use_x3(a, hidden) ? x3_blocks(n) : pick_blocks(hidden, n);
+  const int slabs = blocks;
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
   ReduceArgs r{};
   r.partial = a.partial, r.slabs = slabs, r.slab = slab, r.n_seg = 7, r.overwrite = overwrite;

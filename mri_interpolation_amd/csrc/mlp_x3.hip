@@ -1,0 +1,601 @@
+// Fused tiny-MLP (ReLU) forward + MSE + backward on the bf16 matrix pipe, f32-accurate ("bf16x3",
+// see bf16x3.h): the decoder of BASELINE configs 4 / 5 (32 -> 128 -> 128 -> 1; reference
+// models.py:46-66 training_step, 730-744 HashMLP decoder) in one persistent kernel per step.
+//
+// Same contract as mlp_fused.hip's f32-MFMA kernels (FusedArgs, one slab of partial gradients per
+// workgroup, summed in a fixed order by slab_reduce_kernel), different machine mapping.  Every f32
+// operand is split exactly into three bf16 terms and each product runs as six bf16 MFMAs: 6/16 of
+// the f32 MFMA's cycles at the same accuracy.  The split costs LDS (6 bytes per activation instead
+// of 4, 96 KiB for W2's terms alone), so the roles of mlp_fused.hip are swapped:
+//
+//   * WEIGHTS LIVE IN REGISTERS.  The workgroup is 8 waves, wave w owns hidden units 16 w .. 16 w + 15
+//     in both hidden layers and holds, as ready-made MFMA operand fragments in their three terms,
+//     its rows of W1 and W2 (forward) and its columns of W2 (backward): 108 registers, loaded and
+//     split once per launch.  Its slices of dW2 (16 x 128) and dW1 (16 x 32) are MFMA accumulators
+//     that live across all tiles.
+//   * ACTIVATIONS LIVE IN LDS as three-term bf16 images [32 rows][128 units] (x: [32][32]), written
+//     once by the wave that produced the units and read by all eight: row-wise (ds_read_b128) as
+//     the B operand of the layer chains, transposed (ds_read_b64_tr_b16) where the batch index is
+//     contracted (dW2, dW1).  One XOR swizzle serves both kinds of read and the 8-byte stores.
+//   * v_mfma_f32_16x16x32_bf16 with the weights in the A slot: the accumulator then holds, per lane,
+//     four CONSECUTIVE units of one row -- one packed 8-byte LDS store per term.
+//
+// A 32-row tile takes five workgroup barriers (x ready | h1 | h2 -> y | dz2 | dz1); two waves per
+// SIMD cover each other's LDS latencies, and VALU epilogues (bias, ReLU, the exact split: 5.5
+// instructions per element) of one wave run beside the other's MFMAs.
+#include <algorithm>
+
+#include "bf16x3.h"
+#include "mlp_fused.h"
+
+namespace mri {
+namespace {
+using namespace x3;
+
+constexpr int kX3Threads = 512;
+constexpr int kX3Rows = 32;
+constexpr int kX3H = 128;
+
+// Segment timing for tools/x3_segments.py (a tools-only build with -DMRI_X3_PROFILE; the shipped
+// library compiles these to nothing): shader-clock cycles per barrier-separated segment, split
+// into work (mark -> barrier entry) and wait (barrier entry -> exit), summed over tiles.
+#ifdef MRI_X3_PROFILE
+__device__ long long* g_x3_profile = nullptr;
+constexpr int kX3ProfSlots = 32;
+#define X3P_START const long long p_t0 = clock64();
+#define X3P_BEGIN long long p_t = clock64(); long long p_acc[kX3ProfSlots] = {}; p_acc[20] = p_t - p_t0;
+#define X3P_MARK(i) { const long long p_n = clock64(); p_acc[i] += p_n - p_t; p_t = p_n; }
+#define X3P_SYNC(i) { X3P_MARK(2 * (i)) __syncthreads(); X3P_MARK(2 * (i) + 1) }
+#define X3P_END                                                                               \
+  if (g_x3_profile && (threadIdx.x & 63) == 0) {                                              \
+    long long* dst = g_x3_profile + ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kX3ProfSlots; \
+    for (int q = 0; q < kX3ProfSlots; ++q) dst[q] = p_acc[q];                                 \
+  }
+#else
+#define X3P_START
+#define X3P_BEGIN
+#define X3P_MARK(i)
+#define X3P_SYNC(i) __syncthreads();
+#define X3P_END
+#endif
+
+struct __attribute__((aligned(16))) X3Smem {
+  char x[2][3][kImg32Bytes];  // input tile, double-buffered (the next tile is staged during S7)
+  char h1[3][kImgBytes];
+  char z2[3][kImgBytes];      // dLoss / d(pre-activation 2)
+  char z1[3][kImgBytes];      // dLoss / d(pre-activation 1)
+  char w1[3][4 * kImg32Bytes];  // W1: [hidden unit][input feature]: A operand of layer 1 (row reads) and of dx (transposed)
+  char w2l[4 * kImgBytes];      // the smallest term of W2 [out][in]: read row-wise (layer 2) and transposed (dz1)
+  float ypart[8][kX3Rows];
+  float tgt[2][kX3Rows];
+  float b1[kX3H], b2[kX3H], w3[kX3H];  // read per tile (registers are the scarce resource here)
+};
+
+__device__ __forceinline__ Frag row_frag(const char (*img)[kImgBytes], int off) {
+  Frag f;
+  f.h = lds_read_b128(img[0] + off), f.m = lds_read_b128(img[1] + off), f.l = lds_read_b128(img[2] + off);
+  return f;
+}
+template <int BYTES>
+__device__ __forceinline__ Frag row_frag32(const char (*img)[BYTES], int off) {
+  Frag f;
+  f.h = lds_read_b128(img[0] + off), f.m = lds_read_b128(img[1] + off), f.l = lds_read_b128(img[2] + off);
+  return f;
+}
+__device__ __forceinline__ Frag tr_frag3(const char (*img)[kImgBytes], int c0, int lane) {
+  auto off = [](int row, int ch) { return img_off(row, ch); };
+  Frag f;
+  f.h = tr_frag(img[0], c0, lane, off), f.m = tr_frag(img[1], c0, lane, off), f.l = tr_frag(img[2], c0, lane, off);
+  return f;
+}
+__device__ __forceinline__ Frag tr_frag3_32(const char (*img)[kImg32Bytes], int c0, int lane) {
+  auto off = [](int row, int ch) { return img32_off(row, ch); };
+  Frag f;
+  f.h = tr_frag(img[0], c0, lane, off), f.m = tr_frag(img[1], c0, lane, off), f.l = tr_frag(img[2], c0, lane, off);
+  return f;
+}
+// four consecutive columns of one row, in the three terms
+__device__ __forceinline__ void store4(char (*img)[kImgBytes], int off, const float (&v)[4]) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split2(v[0], v[1], h0, m0, l0);
+  split2(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<u32x2*>(img[0] + off) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(img[1] + off) = u32x2{m0, m1};
+  *reinterpret_cast<u32x2*>(img[2] + off) = u32x2{l0, l1};
+}
+
+// Three-term fragments at byte offset `off` of an image whose terms are TERM bytes apart.
+template <int TERM>
+__device__ __forceinline__ Frag ld_row(const char* img, int off) {
+  Frag f;
+  f.h = lds_read_b128(img + off), f.m = lds_read_b128(img + TERM + off), f.l = lds_read_b128(img + 2 * TERM + off);
+  return f;
+}
+// transposed: rows 4 g .. + 3 at `off`, rows 16 + 4 g .. + 3 HALF bytes further (see tr_frag, bf16x3.h)
+template <int TERM, int HALF>
+__device__ __forceinline__ Frag ld_tr(const char* img, int off) {
+  Frag f;
+  u32x2 a0 = lds_read_tr(img + off), a1 = lds_read_tr(img + off + HALF);
+  u32x2 b0 = lds_read_tr(img + TERM + off), b1 = lds_read_tr(img + TERM + off + HALF);
+  u32x2 c0 = lds_read_tr(img + 2 * TERM + off), c1 = lds_read_tr(img + 2 * TERM + off + HALF);
+  f.h = u32x4{a0[0], a0[1], a1[0], a1[1]};
+  f.m = u32x4{b0[0], b0[1], b1[0], b1[1]};
+  f.l = u32x4{c0[0], c0[1], c1[0], c1[1]};
+  return f;
+}
+__device__ __forceinline__ void st4(char* img, int off, const float (&v)[4]) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split2(v[0], v[1], h0, m0, l0);
+  split2(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<u32x2*>(img + off) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(img + kImgBytes + off) = u32x2{m0, m1};
+  *reinterpret_cast<u32x2*>(img + 2 * kImgBytes + off) = u32x2{l0, l1};
+}
+
+template <bool TRAIN, int U>
+__global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a) {
+  // U = strips of 16 hidden units per wave: 1 -> 8 waves (two per SIMD, 256 registers each),
+  // 2 -> 4 waves (one per SIMD, 512 registers; every activation fragment feeds two strips)
+  constexpr int H = kX3H, WAVES = 8 / U, THREADS = kX3Threads / U;
+  constexpr int IMG = kImgBytes, IMG32 = kImg32Bytes;
+  __shared__ X3Smem sm;
+  X3P_START
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto unit0 = [&](int u) { return 16 * (U * w + u); };  // first hidden unit of the wave's strip u
+
+  // ---- resident weight fragments (A operands: row = unit unit0(u) + li, 8 g + j = contraction)
+  // W2's two larger terms stay in registers (64 per strip, both orientations); its smallest term, used
+  // by one MFMA in six, is read from an LDS image: all three in registers left no room for the fragment
+  // double buffers, and a spilled fragment's reload waits behind every load in flight (vmcnt)
+  u32x4 w2f_h[U][4], w2f_m[U][4], w2t_h[U][4], w2t_m[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int n = unit0(u) + li;
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = a.w2[n * H + 32 * s + 8 * g + j];
+      const Frag f = split8(v);
+      w2f_h[u][s] = f.h, w2f_m[u][s] = f.m;
+    }
+    if (TRAIN) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {  // dz1 = dz2 W2: row = input unit n of layer 2, contraction = its output unit
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a.w2[(32 * s + 8 * g + j) * H + n];
+        const Frag f = split8(v);
+        w2t_h[u][s] = f.h, w2t_m[u][s] = f.m;
+      }
+    }
+  }
+  for (int e = tid; e < H * 32; e += THREADS) {  // W2's third term: row = output unit, 4 inputs per store
+    const int n = e >> 5, c4 = e & 31;
+    const float4 v = *reinterpret_cast<const float4*>(a.w2 + n * H + 4 * c4);
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split2(v.x, v.y, h0, m0, l0);
+    split2(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<u32x2*>(sm.w2l + img_off(n, c4 >> 1) + 8 * (c4 & 1)) = u32x2{l0, l1};
+  }
+  for (int e = tid; e < H * 16; e += THREADS) {  // W1 image: row = hidden unit, pairs of input features
+    const int n = e >> 4, kp = e & 15;
+    const float v0 = 2 * kp < a.k_in ? a.w1[n * a.k_in + 2 * kp] : 0.f;
+    const float v1 = 2 * kp + 1 < a.k_in ? a.w1[n * a.k_in + 2 * kp + 1] : 0.f;
+    uint32_t h, m, l;
+    split2(v0, v1, h, m, l);
+    const int off = img32_off(n, kp >> 2) + 4 * (kp & 3);
+    *reinterpret_cast<uint32_t*>(sm.w1[0] + off) = h;
+    *reinterpret_cast<uint32_t*>(sm.w1[1] + off) = m;
+    *reinterpret_cast<uint32_t*>(sm.w1[2] + off) = l;
+  }
+  if (tid < H) sm.b1[tid] = a.b1[tid], sm.b2[tid] = a.b2[tid], sm.w3[tid] = a.w3[tid];
+  const float b3 = a.b3[0];
+
+  f32x4 g_w2[U][8], g_w1[U][2];
+  float g_b1[U][4], g_b2[U][4], g_w3[U][4], g_b3 = 0.f, loss = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g_w2[u][q] = zero4;
+    g_w1[u][0] = g_w1[u][1] = zero4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g_b1[u][r] = g_b2[u][r] = g_w3[u][r] = 0.f;
+  }
+
+  // ---- LDS addresses.  The XOR swizzles split into a tile-invariant lane part (five registers, below)
+  // and a compile-time part that is XORed / added in at the use: chunk (4 s + g) ^ sw = 4 (s ^ sw>>2) +
+  // (g ^ sw&3), and 64 (s ^ q) = 64 s ^ 64 q, so row-read address (s, t) = (a_row ^ 64 s) + 4096 t; the
+  // transposed reads of 16 columns from chunk 2 k: (a_tr ^ 32 k), rows 16.. 4096 further.  Built
+  // naively from (row, chunk) these addresses were 240 of the tile's 600 VALU instructions.
+  const int q4 = li >> 2, p4 = li & 3, swl = sw(li), trow = 4 * g + q4, swr = sw(trow), swxg = (4 - g) & 3;
+  int a_row = 256 * li + 16 * (g ^ (swl & 3)) + 64 * (swl >> 2);
+  int a_tr = 256 * trow + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (swr & 1)) + 16 * (swr & 14);
+  int a_row32 = 64 * li + 16 * (g ^ ((4 - q4) & 3));                                   // + 1024 t
+  int a_tr32 = 64 * trow + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (swxg & 1)) + 16 * (swxg & 2);  // ^ 32 k, + 1024
+  int a_out[U];                                                                        // + 4096 t
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    a_out[u] = 256 * li + 8 * (g & 1) + 16 * ((g >> 1) ^ (swl & 1)) + ((32 * (U * w + u)) ^ (16 * (swl & 14)));
+  char* const smb = reinterpret_cast<char*>(&sm);
+  char* const i_h1 = smb + offsetof(X3Smem, h1);
+  char* const i_z2 = smb + offsetof(X3Smem, z2);
+  char* const i_z1 = smb + offsetof(X3Smem, z1);
+  const char* const i_w2l = smb + offsetof(X3Smem, w2l);
+  const char* const i_w1 = smb + offsetof(X3Smem, w1);
+
+  // ---- input staging.  Global addresses are a wave-uniform base (SGPRs: the tile's first row) plus a
+  // 32-bit lane offset rebuilt at each use: per-lane 64-bit pointers cost six registers here, were
+  // spilled, and their reloads serialised the loop top behind the input loads' HBM latency.
+  const uint32_t ld32 = (uint32_t)a.ld;  // k_in * ld < 2^30: checked by the launcher
+  float xv[U][2], xt = 0.f;
+  auto load_x = [&](int64_t m0) {
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    const int sb = t_op & 31, skp = t_op >> 5;
+    const float* __restrict__ xs = a.x + m0;
+    const bool live = sb < a.n - m0;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int k = 2 * (skp + (16 / U) * q);
+      xv[q][0] = (live && k < a.k_in) ? xs[(uint32_t)k * ld32 + sb] : 0.f;
+      xv[q][1] = (live && k + 1 < a.k_in) ? xs[(uint32_t)(k + 1) * ld32 + sb] : 0.f;
+    }
+    if (TRAIN) xt = (skp == 0 && live) ? (a.target + m0)[sb] : 0.f;
+  };
+  auto store_x = [&](int buf) {
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    const int sb = t_op & 31, skp = t_op >> 5;
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      uint32_t h, m, l;
+      split2(xv[q][0], xv[q][1], h, m, l);
+      const int kp = skp + (16 / U) * q;
+      const int off = img32_off(sb, kp >> 2) + 4 * (kp & 3);
+      *reinterpret_cast<uint32_t*>(sm.x[buf][0] + off) = h;
+      *reinterpret_cast<uint32_t*>(sm.x[buf][1] + off) = m;
+      *reinterpret_cast<uint32_t*>(sm.x[buf][2] + off) = l;
+    }
+    if (TRAIN && skp == 0) sm.tgt[buf][sb] = xt;
+  };
+
+  const int64_t tiles = (a.n + kX3Rows - 1) / kX3Rows;
+  int buf = 0;
+  load_x((int64_t)blockIdx.x * kX3Rows);
+  store_x(0);
+  X3P_BEGIN
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
+    // opaque per tile: hipcc otherwise materialises every (a_row ^ 64 s) + ... of the tile body once,
+    // outside the loop, and keeps ~30 address registers alive next to the weights
+    asm volatile("" : "+v"(a_row), "+v"(a_tr), "+v"(a_row32), "+v"(a_tr32));
+    const int64_t m0 = tile * kX3Rows;
+    const bool has_next = tile + gridDim.x < tiles;
+    const char* const i_x = smb + offsetof(X3Smem, x) + buf * (3 * IMG32);
+    // the next tile's input: in flight until S7 / the end of the tile.  Training issues it after S2:
+    // hipcc puts an s_waitcnt vmcnt(0) in front of the loads (their destination registers), which at
+    // the loop top would wait for the dx stores of the tile before (stores count in vmcnt too)
+    if (!TRAIN && has_next) load_x((tile + gridDim.x) * kX3Rows);
+    X3P_SYNC(0)  // B0: x[buf] staged; every wave is done with the previous tile's images
+    // Fragments are fetched one group ahead of the MFMAs that use them, into the other half of a
+    // two-entry buffer (pinned with sched_barriers: left alone, hipcc waits for each read right in
+    // front of its MFMA and exposes the LDS latency two or three times per six MFMAs).
+#define X3_PIN __builtin_amdgcn_sched_barrier(0);
+    // ---- S1: h1 = relu(x W1^T + b1) ----------------------------------------------------------------
+    uint32_t mask1 = 0;
+    {
+      Frag w1f[U], xb[2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * (U * w + u));
+      xb[0] = ld_row<IMG32>(i_x, a_row32);
+      xb[1] = ld_row<IMG32>(i_x, a_row32 + 1024);
+      f32x4 bias[U];  // every LDS read of the segment is issued before its first MFMA
+#pragma unroll
+      for (int u = 0; u < U; ++u) bias[u] = *reinterpret_cast<const f32x4*>(&sm.b1[unit0(u) + 4 * g]);
+      X3_PIN
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = mma6(w1f[u], xb[t], zero4);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h[r] = fmaxf(c[u][r] + bias[u][r], 0.f);
+            mask1 |= (h[r] > 0.f ? 1u : 0u) << (8 * u + 4 * t + r);
+          }
+          st4(i_h1, a_out[u] + 4096 * t, h);
+        }
+      }
+    }
+    X3P_SYNC(1)  // B1
+    // ---- S2: h2 = relu(h1 W2^T + b2); this wave's share of y ---------------------------------------
+    float h2[U][2][4];
+    {
+      Frag hb[2];
+      u32x4 wl[U][4];  // W2's third term, rows of this wave's strips
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wl[u][s] = lds_read_b128(i_w2l + (a_row ^ (64 * s)) + 4096 * (U * w + u));
+      hb[0] = ld_row<IMG>(i_h1, a_row);
+      f32x4 bias[U], w3v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bias[u] = *reinterpret_cast<const f32x4*>(&sm.b2[unit0(u) + 4 * g]);
+        w3v[u] = *reinterpret_cast<const f32x4*>(&sm.w3[unit0(u) + 4 * g]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int i = 4 * t + s;
+          if (i < 7) hb[(i + 1) & 1] = ld_row<IMG>(i_h1, (a_row ^ (64 * ((s + 1) & 3))) + 4096 * ((i + 1) >> 2));
+          X3_PIN
+#pragma unroll
+          for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2f_h[u][s], w2f_m[u][s], wl[u][s]}, hb[i & 1], c[u]);
+          X3_PIN
+        }
+        float yp = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h2[u][t][r] = fmaxf(c[u][r] + bias[u][r], 0.f);
+            yp += w3v[u][r] * h2[u][t][r];
+          }
+        yp += __shfl_xor(yp, 16, 64);
+        yp += __shfl_xor(yp, 32, 64);
+        if (g == 0) sm.ypart[w][16 * t + li] = yp;
+      }
+    }
+    if (TRAIN && has_next) load_x((tile + gridDim.x) * kX3Rows);
+    X3P_SYNC(2)  // B2
+    // ---- S4/S5: prediction, loss, dy (every lane for its own row), dz2 of this wave's units --------
+    {
+      float yq[2][WAVES], tg[2] = {0.f, 0.f};  // all LDS reads first: no read -> use -> read chains
+      f32x4 w3v[U];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) yq[t][q] = sm.ypart[q][16 * t + li];
+        if (TRAIN) tg[t] = sm.tgt[buf][16 * t + li];
+      }
+      if (TRAIN) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) w3v[u] = *reinterpret_cast<const f32x4*>(&sm.w3[unit0(u) + 4 * g]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float y = b3;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) y += yq[t][q];
+        const bool live = 16 * t + li < a.n - m0;
+        if (w == 0 && g == 0 && live && a.y) (a.y + m0)[16 * t + li] = y;
+        if (TRAIN) {
+          const float diff = live ? y - tg[t] : 0.f;
+          const float d = diff * a.grad_scale;
+          if (w == 0 && g == 0) {
+            loss += diff * diff;
+            g_b3 += d;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            float z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              g_w3[u][r] += d * h2[u][t][r];
+              const float dw = d * w3v[u][r];
+              z[r] = h2[u][t][r] > 0.f ? dw : 0.f;
+              g_b2[u][r] += z[r];
+            }
+            st4(i_z2, a_out[u] + 4096 * t, z);
+          }
+        }
+      }
+    }
+    if (!TRAIN) {
+      if (has_next) store_x(buf ^ 1);
+      continue;
+    }
+    X3P_SYNC(3)  // B3
+    // ---- S6a: dW2[units][:] += dz2^T h1 (contracts the 32 rows: both operands transposed reads) ------
+    {
+      Frag za[U], hk[2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) za[u] = ld_tr<IMG, 4096>(i_z2, a_tr ^ (32 * (U * w + u)));
+      hk[0] = ld_tr<IMG, 4096>(i_h1, a_tr);
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        if (kt < 7) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
+        X3_PIN
+#pragma unroll
+        for (int u = 0; u < U; ++u) g_w2[u][kt] = mma6(za[u], hk[kt & 1], g_w2[u][kt]);
+        X3_PIN
+      }
+    }
+    // ---- S6b: dz1[:, units] = (dz2 W2) (.) (h1 > 0) -------------------------------------------------
+    {
+      Frag zb[2];
+      // W2^T's third term: lane (li, g) = input unit unit0 + li, output units 32 s + 8 g + j: transposed
+      // read of rows 32 s + 8 g + q (+ 4) of the image; their swizzles differ by sw(q + 4) = sw(q) ^ 9
+      u32x4 wl[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int a0 = 2048 * g + 256 * q4 + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (sw(q4) & 1)) +
+                       ((32 * (U * w + u)) ^ (16 * (sw(q4) & 14)));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const u32x2 lo = lds_read_tr(i_w2l + a0 + 8192 * s), hi = lds_read_tr(i_w2l + (a0 ^ 144) + 8192 * s + 1024);
+          wl[u][s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
+      zb[0] = ld_row<IMG>(i_z2, a_row);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int i = 4 * t + s;
+          if (i < 7) zb[(i + 1) & 1] = ld_row<IMG>(i_z2, (a_row ^ (64 * ((s + 1) & 3))) + 4096 * ((i + 1) >> 2));
+          X3_PIN
+#pragma unroll
+          for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2t_h[u][s], w2t_m[u][s], wl[u][s]}, zb[i & 1], c[u]);
+          X3_PIN
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float z[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            z[r] = ((mask1 >> (8 * u + 4 * t + r)) & 1u) ? c[u][r] : 0.f;
+            g_b1[u][r] += z[r];
+          }
+          st4(i_z1, a_out[u] + 4096 * t, z);
+        }
+      }
+    }
+    X3P_SYNC(4)  // B4
+    // ---- S7: dW1[units][:] += dz1^T x; dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each) ---
+    {
+      const Frag xk = ld_tr<IMG32, 1024>(i_x, a_tr32), x1 = ld_tr<IMG32, 1024>(i_x, a_tr32 ^ 32);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const Frag za = ld_tr<IMG, 4096>(i_z1, a_tr ^ (32 * (U * w + u)));
+        g_w1[u][0] = mma6(za, xk, g_w1[u][0]);
+        g_w1[u][1] = mma6(za, x1, g_w1[u][1]);
+      }
+    }
+    // the next tile's input goes to LDS BEFORE dx is stored: loads and stores share vmcnt, and the
+    // wait for the input loads (issued a whole tile ago) would otherwise wait for those stores too
+    if (has_next) store_x(buf ^ 1);
+    if (a.dx && w < 4) {
+      const int kt = w & 1, bt = w >> 1;
+      f32x4 c = zero4;
+      Frag wa[2], zc[2];
+      // W1^T fragment: lane (li, g) = feature 16 kt + li, units 32 s + 8 g + j: transposed read of rows
+      // 32 s + 8 g + q (+ 4) of the W1 image (64-byte rows, swizzle by (row >> 2) & 3 = 2 g (+ 1))
+      const int aw = 512 * g + 64 * q4 + 8 * (p4 & 1);
+      const int c_lo = (2 * kt + (p4 >> 1)) ^ ((4 - ((2 * g) & 3)) & 3), c_hi = (2 * kt + (p4 >> 1)) ^ ((4 - ((2 * g + 1) & 3)) & 3);
+      auto w1t_frag = [&](int s) {
+        Frag f;
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+          const char* img = i_w1 + term * (4 * IMG32) + aw + 2048 * s;
+          const u32x2 lo = lds_read_tr(img + 16 * c_lo), hi = lds_read_tr(img + 256 + 16 * c_hi);
+          (term == 0 ? f.h : term == 1 ? f.m : f.l) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+        return f;
+      };
+      wa[0] = w1t_frag(0), zc[0] = ld_row<IMG>(i_z1, a_row + 4096 * bt);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+          wa[(s + 1) & 1] = w1t_frag(s + 1);
+          zc[(s + 1) & 1] = ld_row<IMG>(i_z1, (a_row ^ (64 * (s + 1))) + 4096 * bt);
+        }
+        X3_PIN
+        c = mma6(wa[s & 1], zc[s & 1], c);
+        X3_PIN
+      }
+      float* __restrict__ dxs = a.dx + m0;
+      const bool live = 16 * bt + li < a.n - m0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kt + 4 * g + r;
+        if (k < a.k_in && live) dxs[(uint32_t)k * ld32 + 16 * bt + li] = c[r];
+      }
+    }
+  }
+#undef X3_PIN
+  X3P_MARK(18)
+  if (!TRAIN) {
+    X3P_END
+    return;
+  }
+
+  // ---- this workgroup's slab: every element of dW2 / dW1 has exactly one owner lane ----------------
+  float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
+  float* p_w1 = slab;
+  float* p_b1 = p_w1 + H * a.k_in;
+  float* p_w2 = p_b1 + H;
+  float* p_b2 = p_w2 + H * H;
+  float* p_w3 = p_b2 + H;
+  float* p_b3 = p_w3 + H;
+  // per-unit sums: the 16 lanes li of a group hold the 16 (+16) rows' shares, in a fixed order
+  auto rows_sum = [](float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int n = unit0(u) + 4 * g;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p_w2[(n + r) * H + 16 * kt + li] = g_w2[u][kt][r];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + li < a.k_in) p_w1[(n + r) * a.k_in + 16 * kt + li] = g_w1[u][kt][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s1 = rows_sum(g_b1[u][r]), s2 = rows_sum(g_b2[u][r]), s3 = rows_sum(g_w3[u][r]);
+      if (li == 0) p_b1[n + r] = s1, p_b2[n + r] = s2, p_w3[n + r] = s3;
+    }
+  }
+  if (w == 0) {  // only the lanes g == 0 hold non-zero shares
+    const float sb3 = rows_sum(g_b3), sl = rows_sum(loss);
+    if (lane == 0) {
+      p_b3[0] = sb3;
+      p_b3[1] = sl * a.inv_n;
+    }
+  }
+  X3P_MARK(21)
+  X3P_END
+}
+
+}  // namespace
+
+bool x3_supported(int k_in, int hidden) { return hidden == kX3H && k_in >= 1 && k_in <= 32; }
+
+bool x3_addressable(const FusedArgs& a) { return (int64_t)a.k_in * a.ld < (1ll << 30); }
+
+int x3_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kX3Rows), 256); }
+
+int launch_tiny_mlp_x3(const FusedArgs& a, bool train, int blocks, hipStream_t st) {
+  const bool wide = options().mlp_x3 == 2;  // 4 waves of two strips (tools: A/B against 8 x 1)
+  if (train && wide)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+  else if (train)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+  else if (wide)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 2>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+  else
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+  return check_launch("tiny_mlp_x3_kernel");
+}
+
+}  // namespace mri
+
+#ifdef MRI_X3_PROFILE
+extern "C" int mri_debug_set_x3_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mri::g_x3_profile), &device_buffer, sizeof(device_buffer)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#endif

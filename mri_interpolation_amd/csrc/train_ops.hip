@@ -197,6 +197,8 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
     options().bwd_dense_max_parts = value;
   } else if (!strcmp(name, "fwd_pair")) {
     options().fwd_pair = value != 0;
+  } else if (!strcmp(name, "mlp_x3")) {
+    options().mlp_x3 = value;
   } else if (!strcmp(name, "mlp_stagger")) {
     options().mlp_stagger = value;
   } else if (!strcmp(name, "bwd_blocks_per_level")) {
