@@ -270,13 +270,18 @@ int mri_tiny_mlp_train_overlapped(const float* x, const float* target, int64_t n
  * [1 .. n-1] (hidden, hidden), [n] the head (1, hidden); all row-major, 16-byte aligned.
  * act / deriv: HOST arrays of n_sine_layers device pointers to (n, hidden) row-major buffers that
  * receive each sine layer's output and its derivative w0 cos(.) for the backward pass, or both
- * NULL (inference: nothing but y is written).  y: (n) predictions. */
+ * NULL (inference: nothing but y is written).  y: (n) predictions.
+ * workspace: mri_siren_forward_workspace_bytes device bytes, 16-byte aligned (0 bytes / NULL with one
+ * sine layer): each call first splits the hidden x hidden weights there into the three bf16 terms
+ * the matrix pipe multiplies (f32-accurate, csrc/bf16x3.h), in the order the kernel streams them. */
 #define MRI_SIREN_MAX_LAYERS 8
 int mri_siren_supported(int32_t dim_in, int32_t hidden, int32_t n_sine_layers, int32_t dim_out);
+int64_t mri_siren_forward_workspace_bytes(int32_t hidden, int32_t n_sine_layers);
 int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int32_t hidden,
                       int32_t n_sine_layers, const float* const* weight,
                       const float* const* bias, float w0_first, float w0, float* const* act,
-                      float* const* deriv, float* y, void* stream);
+                      float* const* deriv, float* y, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* Backward of the same network (autograd of models.py:230-233 + the loss gradient dy the caller
  * got from mri_mse_loss): dz walks the layers inside LDS (one persistent kernel), each hidden x hidden

@@ -69,7 +69,7 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P, _P, _I32, _P, C.c_uint64, _P, _P, _I64,
                                       _P],
     "mri_siren_forward": [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_P), _F, _F,
-                          C.POINTER(_P), C.POINTER(_P), _P, _P],
+                          C.POINTER(_P), C.POINTER(_P), _P, _P, _I64, _P],
     "mri_siren_backward": [_P, _P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_P),
                            C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _I32, _P, _I64,
                            _P],
@@ -84,6 +84,7 @@ STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
                  "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64],
                  "mri_siren_backward_workspace_bytes": [_I64, _I32, _I32],
+                 "mri_siren_forward_workspace_bytes": [_I32, _I32],
                  "mri_hashgrid_forward_signal_blocks": [C.POINTER(GridDesc), _I64],
                  "mri_tiny_mlp_round_rows": [_I32, _I32, _I64]}
 INT_GETTERS = {"mri_tiny_mlp_supported": [_I32, _I32, _I32],

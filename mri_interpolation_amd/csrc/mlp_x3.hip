@@ -132,6 +132,17 @@ __device__ __forceinline__ void st4(char* img, int off, const float (&v)[4]) {
   *reinterpret_cast<u32x2*>(img + 2 * kImgBytes + off) = u32x2{l0, l1};
 }
 
+// v summed over the four 16-lane groups (lanes li, li + 16, li + 32, li + 48), in every lane: two
+// row swaps (v_permlane16_swap / v_permlane32_swap: one VALU instruction each, no LDS round trip)
+__device__ __forceinline__ float sum_groups(float v) {
+  const uint32_t b = __float_as_uint(v);
+  auto p = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  v = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+  const uint32_t c = __float_as_uint(v);
+  auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 template <bool TRAIN, int U>
 __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a) {
   // U = strips of 16 hidden units per wave: 1 -> 8 waves (two per SIMD, 256 registers each),
@@ -262,57 +273,74 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     if (TRAIN && skp == 0) sm.tgt[buf][sb] = xt;
   };
 
+  // Fragments are fetched one group ahead of the MFMAs that use them, into the other half of a
+  // two-entry buffer (pinned with sched_barriers: left alone, hipcc waits for each read right in
+  // front of its MFMA and exposes the LDS latency two or three times per six MFMAs).
+#define X3_PIN __builtin_amdgcn_sched_barrier(0);
+  // ---- layer 1 of the tile staged in x[xbuf]: h1 = relu(x W1^T + b1) -> image, sign bits -> mask1 ----
+  uint32_t mask1 = 0;
+  auto layer1 = [&](int xbuf) {
+    const char* const i_x = smb + offsetof(X3Smem, x) + xbuf * (3 * IMG32);
+    Frag w1f[U], xb[2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * (U * w + u));
+    xb[0] = ld_row<IMG32>(i_x, a_row32);
+    xb[1] = ld_row<IMG32>(i_x, a_row32 + 1024);
+    f32x4 bias[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) bias[u] = *reinterpret_cast<const f32x4*>(&sm.b1[unit0(u) + 4 * g]);
+    X3_PIN
+    mask1 = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 c[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) c[u] = mma6(w1f[u], xb[t], zero4);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = fmaxf(c[u][r] + bias[u][r], 0.f);
+          mask1 |= (h[r] > 0.f ? 1u : 0u) << (8 * u + 4 * t + r);
+        }
+        st4(i_h1, a_out[u] + 4096 * t, h);
+      }
+    }
+  };
+
+  // A tile takes four workgroup barriers.  A wave's dW2 / dW1 products need the other waves' h1 / x
+  // but only ITS OWN columns of dz2 / dz1 (read back transposed from the image it has just written:
+  // its own LDS writes, which the LDS executes in order: no barrier), so they run in the segment that produces them, beside the
+  // latency-bound loss / ReLU-mask work of the other wave on the SIMD; the next tile's layer 1 runs
+  // beside dx.
+  //   B0 | S2 layer 2 -> y shares | B2 | S5 y, loss, dz2 -> image; stage x(i+1); dW2 |
+  //   B3 | S6 dz1 -> image; dW1 | B4 | S7 dx; layer 1 of tile i+1 | B0 ...
   const int64_t tiles = (a.n + kX3Rows - 1) / kX3Rows;
+  const int64_t stride = gridDim.x;
   int buf = 0;
   load_x((int64_t)blockIdx.x * kX3Rows);
   store_x(0);
+  if (blockIdx.x + stride < tiles) load_x((blockIdx.x + stride) * kX3Rows);  // stays in registers
+  __syncthreads();
+  layer1(0);
   X3P_BEGIN
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, buf ^= 1) {
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride, buf ^= 1) {
     // opaque per tile: hipcc otherwise materialises every (a_row ^ 64 s) + ... of the tile body once,
     // outside the loop, and keeps ~30 address registers alive next to the weights
     asm volatile("" : "+v"(a_row), "+v"(a_tr), "+v"(a_row32), "+v"(a_tr32));
     const int64_t m0 = tile * kX3Rows;
-    const bool has_next = tile + gridDim.x < tiles;
+    const bool has_next = tile + stride < tiles, has_next2 = tile + 2 * stride < tiles;
     const char* const i_x = smb + offsetof(X3Smem, x) + buf * (3 * IMG32);
-    // the next tile's input: in flight until S7 / the end of the tile.  Training issues it after S2:
-    // hipcc puts an s_waitcnt vmcnt(0) in front of the loads (their destination registers), which at
-    // the loop top would wait for the dx stores of the tile before (stores count in vmcnt too)
-    if (!TRAIN && has_next) load_x((tile + gridDim.x) * kX3Rows);
-    X3P_SYNC(0)  // B0: x[buf] staged; every wave is done with the previous tile's images
-    // Fragments are fetched one group ahead of the MFMAs that use them, into the other half of a
-    // two-entry buffer (pinned with sched_barriers: left alone, hipcc waits for each read right in
-    // front of its MFMA and exposes the LDS latency two or three times per six MFMAs).
-#define X3_PIN __builtin_amdgcn_sched_barrier(0);
-    // ---- S1: h1 = relu(x W1^T + b1) ----------------------------------------------------------------
-    uint32_t mask1 = 0;
-    {
-      Frag w1f[U], xb[2];
-#pragma unroll
-      for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * (U * w + u));
-      xb[0] = ld_row<IMG32>(i_x, a_row32);
-      xb[1] = ld_row<IMG32>(i_x, a_row32 + 1024);
-      f32x4 bias[U];  // every LDS read of the segment is issued before its first MFMA
-#pragma unroll
-      for (int u = 0; u < U; ++u) bias[u] = *reinterpret_cast<const f32x4*>(&sm.b1[unit0(u) + 4 * g]);
-      X3_PIN
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        f32x4 c[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = mma6(w1f[u], xb[t], zero4);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          float h[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[r] = fmaxf(c[u][r] + bias[u][r], 0.f);
-            mask1 |= (h[r] > 0.f ? 1u : 0u) << (8 * u + 4 * t + r);
-          }
-          st4(i_h1, a_out[u] + 4096 * t, h);
-        }
-      }
-    }
-    X3P_SYNC(1)  // B1
+    // the input of tile i+1 (in registers since a tile ago) goes to LDS, the loads of tile i+2 start.
+    // Training does this in S5: loads and stores share vmcnt and hipcc waits for ALL of it before the
+    // loads' destination registers are written, which here would mean the dx stores of S7
+    auto stage_next = [&]() {
+      if (has_next) store_x(buf ^ 1);
+      if (has_next2) load_x((tile + 2 * stride) * kX3Rows);
+    };
+    if (!TRAIN) stage_next();
+    X3P_SYNC(0)  // B0: h1 of this tile complete (and, inference, x of the next staged)
     // ---- S2: h2 = relu(h1 W2^T + b2); this wave's share of y ---------------------------------------
     float h2[U][2][4];
     {
@@ -351,14 +379,12 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
             h2[u][t][r] = fmaxf(c[u][r] + bias[u][r], 0.f);
             yp += w3v[u][r] * h2[u][t][r];
           }
-        yp += __shfl_xor(yp, 16, 64);
-        yp += __shfl_xor(yp, 32, 64);
+        yp = sum_groups(yp);
         if (g == 0) sm.ypart[w][16 * t + li] = yp;
       }
     }
-    if (TRAIN && has_next) load_x((tile + gridDim.x) * kX3Rows);
     X3P_SYNC(2)  // B2
-    // ---- S4/S5: prediction, loss, dy (every lane for its own row), dz2 of this wave's units --------
+    // ---- S5: prediction, loss, dy (every lane for its own row), dz2 of this wave's units -----------
     {
       float yq[2][WAVES], tg[2] = {0.f, 0.f};  // all LDS reads first: no read -> use -> read chains
       f32x4 w3v[U];
@@ -402,16 +428,17 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       }
     }
     if (!TRAIN) {
-      if (has_next) store_x(buf ^ 1);
+      if (has_next) layer1(buf ^ 1);  // x(i+1) was staged before B0
       continue;
     }
-    X3P_SYNC(3)  // B3
-    // ---- S6a: dW2[units][:] += dz2^T h1 (contracts the 32 rows: both operands transposed reads) ------
+    stage_next();
+    // ---- S5b: dW2[units][:] += dz2^T h1 (contracts the 32 rows: both operands transposed reads; the
+    //      dz2 columns are this wave's own stores above, and a wave's LDS operations execute in order)
     {
       Frag za[U], hk[2];
+      hk[0] = ld_tr<IMG, 4096>(i_h1, a_tr);
 #pragma unroll
       for (int u = 0; u < U; ++u) za[u] = ld_tr<IMG, 4096>(i_z2, a_tr ^ (32 * (U * w + u)));
-      hk[0] = ld_tr<IMG, 4096>(i_h1, a_tr);
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt) {
         if (kt < 7) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
@@ -421,7 +448,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         X3_PIN
       }
     }
-    // ---- S6b: dz1[:, units] = (dz2 W2) (.) (h1 > 0) -------------------------------------------------
+    X3P_SYNC(3)  // B3
+    // ---- S6: dz1[:, units] = (dz2 W2) (.) (h1 > 0) -------------------------------------------------
     {
       Frag zb[2];
       // W2^T's third term: lane (li, g) = input unit unit0 + li, output units 32 s + 8 g + j: transposed
@@ -464,8 +492,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         }
       }
     }
-    X3P_SYNC(4)  // B4
-    // ---- S7: dW1[units][:] += dz1^T x; dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each) ---
+    // ---- S6b: dW1[units][:] += dz1^T x (this wave's own dz1 columns, as dW2 above) -------------------
     {
       const Frag xk = ld_tr<IMG32, 1024>(i_x, a_tr32), x1 = ld_tr<IMG32, 1024>(i_x, a_tr32 ^ 32);
 #pragma unroll
@@ -475,9 +502,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         g_w1[u][1] = mma6(za, x1, g_w1[u][1]);
       }
     }
-    // the next tile's input goes to LDS BEFORE dx is stored: loads and stores share vmcnt, and the
-    // wait for the input loads (issued a whole tile ago) would otherwise wait for those stores too
-    if (has_next) store_x(buf ^ 1);
+    X3P_SYNC(4)  // B4
+    // ---- S7: dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each); layer 1 of the next tile ---
     if (a.dx && w < 4) {
       const int kt = w & 1, bt = w >> 1;
       f32x4 c = zero4;
@@ -515,6 +541,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         if (k < a.k_in && live) dxs[(uint32_t)k * ld32 + 16 * bt + li] = c[r];
       }
     }
+    if (has_next) layer1(buf ^ 1);
   }
 #undef X3_PIN
   X3P_MARK(18)

@@ -24,8 +24,23 @@
 // so the layer-wise kernels and the chain kernels are interchangeable per layer.
 #include <algorithm>
 
+#include "bf16x3.h"
 #include "common.h"
 #include "device_math.h"
+
+// The H x H products run on the bf16 matrix pipe, f32-accurate (bf16x3.h): every operand is split
+// exactly into three bf16 terms and a 16-deep step is six v_mfma_f32_32x32x16_bf16 -- 6/16 of the f32
+// MFMA's cycles, and VALU work (sincos, the splits) runs beside a bf16 MFMA, which it cannot beside
+// the f32 one.  The WEIGHTS are split once per call by siren_split_weights_kernel into chunk-major
+// term planes that the chunk DMA streams as they are (both orientations: W for the forward products,
+// W^T for dz W); the ACTIVATIONS are split by the consuming lane right after its LDS read (11 VALU
+// instructions per pair: a pre-split image would not fit beside the weight chunks).  The accumulator
+// layout of the 32x32x16 bf16 MFMA is that of the 32x32x2 f32 one, so epilogues are unchanged.
+// The batch-contracting weight gradient splits both operands after the read (MRI_SIREN_X3 = 0
+// builds its f32-MFMA form for A/B runs).
+#ifndef MRI_SIREN_X3
+#define MRI_SIREN_X3 1
+#endif
 
 namespace mri {
 namespace {
@@ -33,7 +48,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 512;  // 8 waves
-constexpr int kKc = 32;        // contraction depth of a weight chunk
+constexpr int kKc = 16;        // contraction depth of a weight chunk: one bf16 MFMA step
+constexpr int kWr = 32;        // batch rows per chunk of the weight-gradient kernel
 constexpr int kMaxSine = MRI_SIREN_MAX_LAYERS;  // sine layers, the first one included
 constexpr int kMaxIn = 8;
 
@@ -49,7 +65,7 @@ struct Shape {
   static constexpr int rows = 32 * RB;              // rows of a tile: 64, 128, 256, 256
   static constexpr int ld = H + 4;                  // image row stride: rows 4 banks apart (mod 64)
   static constexpr int chunks = H / kKc;            // weight chunks per layer
-  static constexpr int pieces = H / 8;              // 1-KiB DMA pieces of a 32 x H / H x 32 chunk
+  static constexpr int chunk_bytes = 3 * H * 32;    // a weight chunk: three term planes of [H][16] bf16
   static constexpr int groups = kThreads / H;       // row groups of the (column, row group) phases
   static constexpr int rpt = rows / groups;         // rows per thread there: 32 (16 for H = 32)
   static constexpr int drip = 16 / chunks;          // accumulator registers dripped per chunk
@@ -72,6 +88,7 @@ struct ChainArgs {
   float grad_scale, inv_n;          // 2 / (n_total divisor), 1 / n_total
   float* dz_last;                   // (n, H): dLoss / d(pre-activation of the last sine layer)
   float* partial;                   // [gridDim.x][fwd_slab_floats]
+  const char* wsplit;               // split W of layers 1 .. n_sine-1 (split_matrix_bytes each)
 };
 
 // loss-mode slab: dW_head [H] | db_last [H] | db_head, loss (padded to 4)
@@ -79,7 +96,7 @@ __host__ __device__ inline int fwd_slab_floats(int hidden) { return 2 * hidden +
 
 template <class S>
 struct FwdSmem {
-  float wbuf[2][S::H * kKc];        // weight chunks [n][32] with 16-byte slots XOR-swizzled
+  char wbuf[2][S::chunk_bytes] __attribute__((aligned(16)));  // weight chunks: term planes [n][2 slots of 8 bf16]
   float img[S::rows * S::ld];       // activation image of the tile
   float xs[S::rows * kMaxIn];
   float bias[kMaxSine][S::H];
@@ -90,57 +107,68 @@ struct FwdSmem {
 // row of register r of a 32x32 accumulator: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-// Queue the LDS-DMA of chunk (weights w of one layer, columns [32 kc, 32 kc + 32)) into `dst`:
-// pieces of 8 rows x 128 B; lane = (row in piece, 16-byte slot); the slot a lane FETCHES is its
-// LDS slot XOR ((row >> 1) & 7), the involution the fragment reads undo: the 16 rows a
-// ds_read_b128 lane group touches then fall on 16 different 16-byte slots of the 256-byte bank row.
+// acc += A B over a 16-deep step, operands in their three bf16 terms: the six products, smallest first
+__device__ __forceinline__ f32x16 mfma32x3(const x3::u32x4& a, const x3::u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3::bf16x8, a),
+                                                 __builtin_bit_cast(x3::bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma6_32(const x3::Frag& a, const x3::Frag& b, f32x16 c) {
+  c = mfma32x3(a.l, b.h, c);
+  c = mfma32x3(a.h, b.l, c);
+  c = mfma32x3(a.m, b.m, c);
+  c = mfma32x3(a.m, b.h, c);
+  c = mfma32x3(a.h, b.m, c);
+  c = mfma32x3(a.h, b.h, c);
+  return c;
+}
+__device__ __forceinline__ x3::Frag split_octets(const float4& lo, const float4& hi) {
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return x3::split8(v);
+}
+
+// Split weights (siren_split_weights_kernel): per H x H matrix, chunk kc = contraction indices
+// [16 kc, 16 kc + 16), term planes h | m | l of [H rows][2 slots][8 bf16]; slot q of row n holds
+// contraction indices 16 kc + 4 q + e and 16 kc + 8 + 4 q + e (e = 0..3): the eight positions lane
+// half q of a 32x32x16 MFMA contracts when the other operand is read from the f32 image as two
+// 16-byte fragments at k = 4 q and 8 + 4 q.  A chunk is contiguous: 3 x H x 32 bytes.
+__host__ __device__ inline int64_t split_matrix_bytes(int H) { return (int64_t)(H / kKc) * 3 * H * 32; }
+
+// Queue the LDS-DMA of chunk kc of one split matrix into `dst`: 16-byte slots, lane = slot.  The
+// slot a lane FETCHES is its LDS slot with the half bit XORed by bit 3 of the row, the involution
+// the fragment reads undo: the 16 lanes of a ds_read_b128 group then touch 16 different slots.
 template <class S>
-__device__ __forceinline__ void issue_chunk(const float* __restrict__ w, int kc, float* dst,
+__device__ __forceinline__ void issue_chunk(const char* __restrict__ wsplit, int kc, char* dst,
                                             int wave, int lane) {
+  constexpr int slots = 6 * S::H;  // 3 planes x H rows x 2
+  const char* src = wsplit + (int64_t)kc * S::chunk_bytes;
 #pragma unroll
-  for (int i = 0; i < (S::pieces + 7) / 8; ++i) {
-    const int piece = wave + 8 * i;
-    if (S::pieces % 8 != 0 && piece >= S::pieces) break;  // H = 32: four pieces, four waves
-    const int n = piece * 8 + (lane >> 3);
-    const int q = (lane & 7) ^ ((n >> 1) & 7);
+  for (int i = 0; i < (slots + kThreads - 1) / kThreads; ++i) {
+    const int base = (wave + 8 * i) * 64;
+    if (slots % kThreads != 0 && base >= slots) break;
+    const int slot = base + lane, n = (slot >> 1) % S::H;
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(w + n * S::H + kc * kKc + q * 4),
-        (__attribute__((address_space(3))) void*)(dst + piece * 8 * kKc), 16, 0, 0);
+        (const __attribute__((address_space(1))) void*)(src + 16 * (slot ^ ((n >> 3) & 1))),
+        (__attribute__((address_space(3))) void*)(dst + 16 * base), 16, 0, 0);
   }
 }
 
-// One 32-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x CT tile.
-// Lane half lh takes k = 8 j + 4 lh + e of octet j (element e of its 16-byte fragment): the two
-// halves of an MFMA's 2-deep contraction are k and k + 4.
-template <int NT>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], const float* __restrict__ a_row,
-                                          const float* __restrict__ wb, const int (&nb)[NT],
-                                          const int (&sw)[NT], int lh) {
-  float4 av[2], bv[2][NT];
-  auto fetch = [&](int buf, int j) {
-    av[buf] = *reinterpret_cast<const float4*>(a_row + 8 * j);
+// One 16-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x CT tile.  a_k: the
+// lane's image row at the chunk's first k, + 4 lh; boff[t]: byte offset of the lane's slot of its
+// column 32 t in a term plane.
+template <int NT, int H>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], const float* __restrict__ a_k,
+                                          const char* __restrict__ wb, const int (&boff)[NT]) {
+  const float4 a_lo = *reinterpret_cast<const float4*>(a_k), a_hi = *reinterpret_cast<const float4*>(a_k + 8);
+  x3::Frag fb[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      bv[buf][t] = *reinterpret_cast<const float4*>(wb + nb[t] + (((2 * j + lh) ^ sw[t]) << 2));
-  };
-  auto compute = [&](int buf) {
-    const float ae[4] = {av[buf].x, av[buf].y, av[buf].z, av[buf].w};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float be[4] = {bv[buf][t].x, bv[buf][t].y, bv[buf][t].z, bv[buf][t].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], be[e], acc[t], 0, 0, 0);
-    }
-  };
-  fetch(0, 0);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j + 1 < 4) fetch((j + 1) & 1, j + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(j & 1);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < NT; ++t) {
+    fb[t].h = *reinterpret_cast<const x3::u32x4*>(wb + boff[t]);
+    fb[t].m = *reinterpret_cast<const x3::u32x4*>(wb + H * 32 + boff[t]);
+    fb[t].l = *reinterpret_cast<const x3::u32x4*>(wb + 2 * H * 32 + boff[t]);
   }
+  const x3::Frag fa = split_octets(a_lo, a_hi);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = mma6_32(fa, fb[t], acc[t]);
 }
 
 // Phase timing for tools/siren_phases.py (a tools-only build with -DSIREN_PROFILE; the shipped
@@ -186,13 +214,13 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
   // this lane's fragment addresses
   const float* a_row = sm.img + (rb * 32 + l31) * S::ld + 4 * lh;
   const int n0 = cb * S::CT + l31;  // column of tile 0; tile t: + 32 t
-  int nb[NT], sw[NT];
+  int boff[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) nb[t] = (n0 + 32 * t) * kKc, sw[t] = ((n0 + 32 * t) >> 1) & 7;
+  for (int t = 0; t < NT; ++t) boff[t] = 32 * (n0 + 32 * t) + 16 * (lh ^ (((n0 + 32 * t) >> 3) & 1));
 
   // chunk stream: chunk s (layer 1 + (s / chunks) % n_mm, columns 32 (s % chunks)) lives in wbuf[s & 1]
   int s = 0;
-  if (n_mm > 0 && (int64_t)blockIdx.x < tiles) issue_chunk<S>(a.w[1], 0, sm.wbuf[0], wave, lane);
+  if (n_mm > 0 && (int64_t)blockIdx.x < tiles) issue_chunk<S>(a.wsplit, 0, sm.wbuf[0], wave, lane);
 
   // activations waiting to leave for HBM (STORE): the outputs of MFMA layer `pend_l` of the tile
   // at `pend_m0`, dripped out a few registers per chunk beside the next layer's MFMAs
@@ -295,12 +323,13 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
           const bool more_k = kc + 1 < S::chunks;
           const int nl = more_k ? l : (l < n_mm ? l + 1 : 1);
           if (more_k || l < n_mm || tile + gridDim.x < tiles)
-            issue_chunk<S>(a.w[nl], more_k ? kc + 1 : 0, sm.wbuf[(s + 1) & 1], wave, lane);
+            issue_chunk<S>(a.wsplit + (nl - 1) * split_matrix_bytes(H), more_k ? kc + 1 : 0,
+                           sm.wbuf[(s + 1) & 1], wave, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         drip(kc * S::drip, (kc + 1) * S::drip, full_tile);
         SP_MARK(3)  // DMA issue + dripped stores
-        mma_chunk<NT>(acc, a_row + kc * kKc, sm.wbuf[s & 1], nb, sw, lh);
+        mma_chunk<NT, H>(acc, a_row + kc * kKc, sm.wbuf[s & 1], boff);
         SP_MARK(4)  // fragment reads + MFMAs
       }
       pend_l = -1;  // fully dripped
@@ -449,6 +478,7 @@ struct BwdArgs {
   const float* deriv[kMaxSine];    // (n, H) per sine layer: w0 cos(.)
   float* dz[kMaxSine];             // (n, H) for sine layers 1 .. n_sine-1 ([0] unused)
   float* partial;                  // [gridDim.x][bwd_slab_floats]
+  const char* wtsplit;             // split W^T of layers 1 .. n_sine-1 (split_matrix_bytes each)
   int head_done;                   // dz[n_sine-1] is an INPUT (the forward kernel's loss mode wrote it)
 };
 
@@ -459,58 +489,13 @@ __host__ __device__ inline int bwd_slab_floats(int hidden, int n_sine) {
 
 template <class S>
 struct BwdSmem {
-  float wbuf[2][kKc * S::H];        // weight chunks [32 rows n][H]
+  char wbuf[2][S::chunk_bytes] __attribute__((aligned(16)));  // chunks of the split W^T: term planes [k][2 slots]
   float img[S::rows * S::ld];
   float xs[S::rows * kMaxIn];
   float w_last[S::H];
   float dy[S::rows];
   float gb[kMaxSine][S::RB][S::H];  // bias-gradient column sums per layer and row block (sole owners)
 };
-
-// a chunk [32 rows][H] of an untransposed weight matrix is ONE contiguous block of W
-template <class S>
-__device__ __forceinline__ void issue_rows(const float* __restrict__ w, int kc, float* dst,
-                                           int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < (S::pieces + 7) / 8; ++i) {
-    const int piece = wave + 8 * i;
-    if (S::pieces % 8 != 0 && piece >= S::pieces) break;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(w + kc * kKc * S::H + piece * 256 + lane * 4),
-        (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
-  }
-}
-
-// acc[t] += img[rows][n] * W[n][cols_t] over the chunk's 32 contraction indices n
-template <int NT, int H>
-__device__ __forceinline__ void mma_chunk_rows(f32x16 (&acc)[NT], const float* __restrict__ a_row,
-                                               const float* __restrict__ wb_lane) {
-  float4 av[2];
-  float bv[2][NT][4];
-  auto fetch = [&](int buf, int j) {
-    av[buf] = *reinterpret_cast<const float4*>(a_row + 8 * j);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[buf][t][e] = wb_lane[(8 * j + e) * H + 32 * t];
-  };
-  auto compute = [&](int buf) {
-    const float ae[4] = {av[buf].x, av[buf].y, av[buf].z, av[buf].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], bv[buf][t][e], acc[t], 0, 0, 0);
-  };
-  fetch(0, 0);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j + 1 < 4) fetch((j + 1) & 1, j + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(j & 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 
 template <class S>
 __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs a) {
@@ -527,6 +512,9 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
   const float* a_row = sm.img + (rb * 32 + l31) * S::ld + 4 * lh;
   const int n0 = cb * S::CT + l31;
   const int lane_off = (rb * 32 + 4 * lh) * H + n0;  // element (row of register 0, column n0)
+  int boff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) boff[t] = 32 * (n0 + 32 * t) + 16 * (lh ^ (((n0 + 32 * t) >> 3) & 1));
   const int col = tid % H, r0 = (tid / H) * S::rpt;  // VALU phases: (column, group of rows)
 
   // running sums of this workgroup
@@ -537,7 +525,8 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
   for (int d = 0; d < kMaxIn; ++d) g_wfirst[d] = 0.f;
 
   int s = 0;
-  if (L > 1 && (int64_t)blockIdx.x < tiles) issue_rows<S>(a.w[L - 1], 0, sm.wbuf[0], wave, lane);
+  if (L > 1 && (int64_t)blockIdx.x < tiles)
+    issue_chunk<S>(a.wtsplit + (L - 2) * split_matrix_bytes(H), 0, sm.wbuf[0], wave, lane);
 
   float pz[NT][16];  // dz waiting to leave for HBM, dripped beside the next layer's MFMAs
   int pend_l = -1;
@@ -642,12 +631,13 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
           const bool more_k = kc + 1 < S::chunks;
           const int nl = more_k ? l : (l > 1 ? l - 1 : L - 1);
           if (more_k || l > 1 || tile + gridDim.x < tiles)
-            issue_rows<S>(a.w[nl], more_k ? kc + 1 : 0, sm.wbuf[(s + 1) & 1], wave, lane);
+            issue_chunk<S>(a.wtsplit + (nl - 1) * split_matrix_bytes(H), more_k ? kc + 1 : 0,
+                           sm.wbuf[(s + 1) & 1], wave, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         drip(kc * S::drip, (kc + 1) * S::drip, full_tile);
         if (kc == 0) load_deriv(a.deriv[l - 1], m0, full_tile, dv);  // lands beside the MFMAs
-        mma_chunk_rows<NT, H>(acc, a_row + kc * kKc, sm.wbuf[s & 1] + 4 * lh * H + n0);
+        mma_chunk<NT, H>(acc, a_row + kc * kKc, sm.wbuf[s & 1], boff);
       }
       pend_l = -1;
 #pragma unroll
@@ -794,8 +784,8 @@ struct WgradShape {
 
 template <class W>
 struct WgradSmem {
-  float z[2][kKc * W::H];
-  float a[2][kKc * W::H];
+  float z[2][kWr * W::H];
+  float a[2][kWr * W::H];
 };
 
 template <class W>
@@ -809,7 +799,7 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
   const int tile = W::wide ? 0 : wave % W::tiles, split = W::wide ? 0 : wave / W::tiles;
   const int n_base = W::wide ? (wave >> 1) * TI * 32 : (tile / W::TD) * 32;
   const int k_base = W::wide ? (wave & 1) * TJ * 32 : (tile % W::TD) * 32;
-  const int64_t chunks = (g.n + kKc - 1) / kKc;
+  const int64_t chunks = (g.n + kWr - 1) / kWr;
   const int64_t per = (chunks + gridDim.x - 1) / gridDim.x;
   const int64_t c_lo = (int64_t)blockIdx.x * per, c_hi = c_lo + per < chunks ? c_lo + per : chunks;
 
@@ -827,7 +817,7 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
       const int piece = wave + 8 * i;
       if (W::pieces % 8 != 0 && piece >= W::pieces) break;
       // a piece is 256 / H rows of the chunk (one row at H = 256: the row index is then wave-uniform)
-      int64_t row = c * kKc + piece * (256 / H) + (lane * 4) / H;
+      int64_t row = c * kWr + piece * (256 / H) + (lane * 4) / H;
       if (row >= g.n) row = g.n - 1;  // stays inside the buffers; such rows are zeroed below
       const int64_t src = row * H + (lane * 4) % H;
       __builtin_amdgcn_global_load_lds(
@@ -844,14 +834,48 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // chunk c landed for every wave; the other buffer is free
     if (c + 1 < c_hi) issue(c + 1, buf ^ 1);
-    if ((c + 1) * kKc > g.n) {  // the batch ends inside this chunk: rows beyond it contribute 0
-      const int live = (int)(g.n - c * kKc);
-      for (int e = tid; e < (kKc - live) * H; e += kThreads) sm.z[buf][live * H + e] = 0.f;
+    if ((c + 1) * kWr > g.n) {  // the batch ends inside this chunk: rows beyond it contribute 0
+      const int live = (int)(g.n - c * kWr);
+      for (int e = tid; e < (kWr - live) * H; e += kThreads) sm.z[buf][live * H + e] = 0.f;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     const float* zp = sm.z[buf] + lh * H + n_base + l31;
     const float* ap = sm.a[buf] + lh * H + k_base + l31;
+    constexpr int kPairs = kWr / 2 / RS;  // row pairs of this wave: split, split + RS, ...
+#if MRI_SIREN_X3
+    if constexpr (kPairs % 8 == 0) {
+      // a 16-deep step contracts eight of the wave's row pairs: lane half lh holds row 2 pair + lh,
+      // element j of both operands = pair split + (8 s + j) RS
+#pragma unroll
+      for (int s = 0; s < kPairs / 8; ++s) {
+        x3::Frag fz[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = zp[2 * (split + (8 * s + j) * RS) * H + ti * 32];
+          fz[ti] = x3::split8(v);
+        }
+        float raw[2][8];
+        auto fetch_a = [&](int b, int tj) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) raw[b][j] = ap[2 * (split + (8 * s + j) * RS) * H + tj * 32];
+        };
+        fetch_a(0, 0);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          if (tj + 1 < TJ) fetch_a((tj + 1) & 1, tj + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const x3::Frag fa = x3::split8(raw[tj & 1]);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) acc[ti][tj] = mma6_32(fz[ti], fa, acc[ti][tj]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      continue;
+    }
+#endif
     float zv[2][TI], av[2][TJ];
     auto fetch = [&](int b, int rp) {
 #pragma unroll
@@ -866,7 +890,6 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
         for (int tj = 0; tj < TJ; ++tj)
           acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(zv[b][ti], av[b][tj], acc[ti][tj], 0, 0, 0);
     };
-    constexpr int kPairs = kKc / 2 / RS;  // row pairs of this wave: split, split + RS, ...
     fetch(0, split);
 #pragma unroll
     for (int q = 0; q < kPairs; ++q) {
@@ -906,6 +929,53 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   dst[e] += sum;
 }
 
+// Three-term split of the H x H weights into the chunk-major planes issue_chunk streams (layout:
+// split_matrix_bytes).  transposed: the planes of W^T (row = input unit k, contraction = output unit).
+struct SplitArgs {
+  const float* w[kMaxSine];
+  int count, H, transposed;
+  char* out;
+};
+
+__global__ __launch_bounds__(256) void siren_split_weights_kernel(const SplitArgs g) {
+  const int H = g.H, per = H * (H / kKc) * 2;
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= g.count * per) return;
+  const int m = id / per, e = id % per;
+  const int q = e & 1, row = (e >> 1) % H, kc = (e >> 1) / H;
+  const float* w = g.w[m];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kKc * kc + 8 * (j >> 2) + 4 * q + (j & 3);
+    v[j] = g.transposed ? w[k * H + row] : w[row * H + k];
+  }
+  const x3::Frag f = x3::split8(v);
+  char* dst = g.out + m * split_matrix_bytes(H) + (int64_t)kc * 3 * H * 32 + row * 32 + 16 * q;
+  *reinterpret_cast<x3::u32x4*>(dst) = f.h;
+  *reinterpret_cast<x3::u32x4*>(dst + H * 32) = f.m;
+  *reinterpret_cast<x3::u32x4*>(dst + 2 * H * 32) = f.l;
+}
+
+int split_weights(const float* const* weight, int n_sine, int hidden, bool transposed, char* out,
+                  hipStream_t st) {
+  if (n_sine < 2) return MRI_OK;
+  SplitArgs g{};
+  g.count = n_sine - 1, g.H = hidden, g.transposed = transposed ? 1 : 0, g.out = out;
+  for (int l = 1; l < n_sine; ++l) g.w[l - 1] = weight[l];
+  const int threads = g.count * hidden * (hidden / kKc) * 2;
+  hipLaunchKernelGGL(siren_split_weights_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0,
+                     st, g);
+  return check_launch("siren_split_weights_kernel");
+}
+
+int64_t split_region_bytes(int hidden, int n_sine) {
+  return n_sine > 1 ? (n_sine - 1) * split_matrix_bytes(hidden) : 0;
+}
+
+// workspace of the training entry points: [slabs of partial sums][split weights]
+int64_t slab_region_bytes(int64_t n, int hidden, int n_sine);
+
 // ------------------------------------------------------------------------------ host side
 bool chain_supported(int dim_in, int hidden, int n_sine, int dim_out) {
   return (hidden == 32 || hidden == 64 || hidden == 128 || hidden == 256) && dim_in >= 1 &&
@@ -915,7 +985,7 @@ bool chain_supported(int dim_in, int hidden, int n_sine, int dim_out) {
 int tile_rows(int hidden) { return hidden >= 256 ? 64 : hidden == 128 ? 128 : 256; }
 int wgrad_split(int hidden) { return hidden >= 128 ? 1 : hidden == 64 ? 2 : 8; }
 int chain_blocks(int hidden, int64_t n) { return (int)std::min<int64_t>(ceil_div(n, tile_rows(hidden)), 256); }
-int wgrad_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kKc), 256); }
+int wgrad_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kWr), 256); }
 
 template <int H>
 int launch_forward(const ChainArgs& a, int mode, hipStream_t st) {
@@ -1013,13 +1083,19 @@ extern "C" int mri_siren_supported(int32_t dim_in, int32_t hidden, int32_t n_sin
 extern "C" int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int32_t hidden,
                                  int32_t n_sine_layers, const float* const* weight,
                                  const float* const* bias, float w0_first, float w0,
-                                 float* const* act, float* const* deriv, float* y, void* stream) {
+                                 float* const* act, float* const* deriv, float* y, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
   MRI_REQUIRE(chain_supported(dim_in, hidden, n_sine_layers, 1),
               "fused SIREN chain: %d -> %d x %d -> 1 is not supported (hidden 32 / 64 / 128 / 256, "
               "dim_in <= 8, <= %d sine layers)", dim_in, hidden, n_sine_layers, kMaxSine);
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   if (n == 0) return MRI_OK;
   MRI_REQUIRE(x && weight && bias && y, "NULL pointer");
+  const int64_t need = split_region_bytes(hidden, n_sine_layers);
+  MRI_REQUIRE(need == 0 || (workspace && workspace_bytes >= need &&
+                            (reinterpret_cast<uintptr_t>(workspace) & 15) == 0),
+              "SIREN forward needs a 16-byte aligned workspace of %lld bytes "
+              "(mri_siren_forward_workspace_bytes)", (long long)need);
   MRI_REQUIRE((act == nullptr) == (deriv == nullptr), "act and deriv go together");
   ChainArgs a{};
   a.x = x, a.n = n, a.dim_in = dim_in, a.n_sine = n_sine_layers;
@@ -1035,7 +1111,16 @@ extern "C" int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int3
       MRI_REQUIRE(act[l] && deriv[l], "NULL activation buffer (layer %d)", l);
       a.act[l] = act[l], a.deriv[l] = deriv[l];
     }
+  a.wsplit = static_cast<const char*>(workspace);
+  if (int rc = split_weights(weight, n_sine_layers, hidden, false, static_cast<char*>(workspace),
+                             (hipStream_t)stream))
+    return rc;
   return forward_any(hidden, a, act != nullptr ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t mri_siren_forward_workspace_bytes(int32_t hidden, int32_t n_sine_layers) {
+  if (!chain_supported(1, hidden, n_sine_layers, 1)) return -1;
+  return split_region_bytes(hidden, n_sine_layers);
 }
 
 extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64_t n,
@@ -1054,9 +1139,11 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   MRI_REQUIRE(x && target && weight && bias && act && deriv && dz_last && y && d_w_head &&
                   d_b_head && d_b_last && loss_out, "NULL pointer");
   const int blocks = chain_blocks(hidden, n);
-  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)blocks * fwd_slab_floats(hidden) * 4,
-              "SIREN forward with loss needs a workspace of %lld bytes",
-              (long long)blocks * fwd_slab_floats(hidden) * 4);
+  const int64_t need = mri_siren_backward_workspace_bytes(n, hidden, n_sine_layers);
+  MRI_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "SIREN forward with loss needs a 16-byte aligned workspace of %lld bytes "
+              "(mri_siren_backward_workspace_bytes)", (long long)need);
+  char* const wsplit = static_cast<char*>(workspace) + slab_region_bytes(n, hidden, n_sine_layers);
   ChainArgs a{};
   a.x = x, a.n = n, a.dim_in = dim_in, a.n_sine = n_sine_layers;
   a.w0_first = w0_first, a.w0 = w0, a.y = y;
@@ -1074,6 +1161,8 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
     a.act[l] = act[l], a.deriv[l] = deriv[l];
   }
   hipStream_t st = (hipStream_t)stream;
+  a.wsplit = wsplit;
+  if (int rc = split_weights(weight, n_sine_layers, hidden, false, wsplit, st)) return rc;
   if (int rc = forward_any(hidden, a, 2, st)) return rc;
   FwdReduceArgs r{};
   r.partial = a.partial, r.slabs = blocks, r.hidden = hidden;
@@ -1083,13 +1172,20 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   return check_launch("siren_fwd_reduce_kernel");
 }
 
+namespace mri {
+namespace {
+int64_t slab_region_bytes(int64_t n, int hidden, int n_sine) {
+  const int64_t chain = (int64_t)chain_blocks(hidden, n) * bwd_slab_floats(hidden, n_sine);
+  const int64_t wgrad = n_sine > 1 ? (int64_t)wgrad_blocks(n) * wgrad_split(hidden) * hidden * hidden : 0;
+  return (std::max(chain, wgrad) * 4 + 255) / 256 * 256;
+}
+}  // namespace
+}  // namespace mri
+
 extern "C" int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t hidden,
                                                       int32_t n_sine_layers) {
   if (n < 1 || !chain_supported(1, hidden, n_sine_layers, 1)) return -1;
-  const int64_t chain = (int64_t)chain_blocks(hidden, n) * bwd_slab_floats(hidden, n_sine_layers);
-  const int64_t wgrad = n_sine_layers > 1
-                            ? (int64_t)wgrad_blocks(n) * wgrad_split(hidden) * hidden * hidden : 0;
-  return std::max(chain, wgrad) * 4;
+  return slab_region_bytes(n, hidden, n_sine_layers) + split_region_bytes(hidden, n_sine_layers);
 }
 
 extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, int32_t dim_in,
@@ -1109,10 +1205,11 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
               "NULL pointer");
   const int L = n_sine_layers;
   const int64_t need = mri_siren_backward_workspace_bytes(n, hidden, L);
-  MRI_REQUIRE(workspace && workspace_bytes >= need,
-              "SIREN backward needs a workspace of %lld bytes (mri_siren_backward_workspace_bytes)",
-              (long long)need);
+  MRI_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "SIREN backward needs a 16-byte aligned workspace of %lld bytes "
+              "(mri_siren_backward_workspace_bytes)", (long long)need);
   hipStream_t st = (hipStream_t)stream;
+  char* const wtsplit = static_cast<char*>(workspace) + slab_region_bytes(n, hidden, L);
   BwdArgs a{};
   a.x = x, a.dy = dy, a.n = n, a.dim_in = dim_in, a.n_sine = L;
   a.partial = static_cast<float*>(workspace);
@@ -1133,6 +1230,8 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   }
   a.act_last = head_done ? nullptr : act[L - 1];
   a.head_done = head_done ? 1 : 0;
+  a.wtsplit = wtsplit;
+  if (int rc = split_weights(weight, L, hidden, true, wtsplit, st)) return rc;
   if (int rc = backward_any(hidden, a, st)) return rc;
   BwdReduceArgs r{};
   r.partial = a.partial, r.slabs = chain_blocks(hidden, n), r.hidden = hidden, r.n_sine = L;

@@ -519,10 +519,12 @@ def siren_forward(x, weights, biases, w0_first: float, w0: float, act=None, deri
     if (act is None) != (deriv is None) or (act is not None and
                                             (len(act) != n_sine or len(deriv) != n_sine)):
         raise ValueError("act and deriv: one (n, hidden) buffer per sine layer, or both None")
+    ws = _siren_scratch(x.device, max(n, 1), hidden, n_sine)  # holds the split weights
     _lib.call("mri_siren_forward", _ptr(x), n, dim_in, hidden, n_sine, _ptr_array(weights),
               _ptr_array(biases), float(w0_first), float(w0),
               _ptr_array(act) if act is not None else None,
-              _ptr_array(deriv) if deriv is not None else None, _ptr(y), _stream())
+              _ptr_array(deriv) if deriv is not None else None, _ptr(y), _ptr(ws), ws.numel() * 4,
+              _stream())
     return y
 
 

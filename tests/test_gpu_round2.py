@@ -244,13 +244,28 @@ def test_encoder_coordinate_gradient(amd, name):
     assert torch.equal(xg2.grad, xg.grad)
 
 
+def _set_option(name, value):
+    from mri_interpolation_amd import _lib
+    _lib.set_option(name, value)
+
+
 # ------------------------------------------------------- lookup and decoder running side by side
 @pytest.mark.parametrize("dim,n", [(3, 1 << 18), (3, 100001), (3, 5000), (3, 33), (4, 70000), (2, 40000)])
 def test_overlapped_lookup_and_decoder_equal_the_sequential_step(amd, dim, n):
     """The hash-grid lookup runs on its own stream BESIDE the decoder kernel, which waits slice by
     slice on agent-scope counters (mri_hashgrid_forward_signal / mri_tiny_mlp_train_overlapped):
     same features, loss, gradients and parameters as lookup-then-decoder, bit for bit, over
-    several steps (the counters only ever grow), for full, ragged and sub-slice batches."""
+    several steps (the counters only ever grow), for full, ragged and sub-slice batches.  The
+    overlapped form is the f32-MFMA team kernel's, so the sequential step runs that kernel too
+    (option mlp_x3 = 0; the bf16x3 kernel sums in another order)."""
+    _set_option("mlp_x3", 0)
+    try:
+        _overlap_equals_sequential(amd, dim, n)
+    finally:
+        _set_option("mlp_x3", 1)
+
+
+def _overlap_equals_sequential(amd, dim, n):
     torch.manual_seed(dim * 1000 + n % 997)
     net = amd.models.HashMLP(dim, 16, 2, 17, 16, 512, dim_hidden=128, n_layers=3,
                              activation=torch.nn.ReLU, batch_norm=False, final_activation=False,
@@ -277,6 +292,54 @@ def test_overlapped_lookup_and_decoder_equal_the_sequential_step(amd, dim, n):
     la, lb = steps[0].train_step(x, y), steps[1].train_step(x, y)
     assert float(la) == float(lb) and torch.equal(steps[0].flat.param, steps[1].flat.param)
     steps[0].check_status()
+
+
+@pytest.mark.parametrize("n", [1 << 18, 70001, 33])
+def test_decoder_kernels_agree(amd, n):
+    """The three decoder kernels for 32 -> 128 -> 128 -> 1 (option mlp_x3: 0 = f32 MFMA team kernel,
+    1 = bf16x3 with 8 waves, 2 = bf16x3 with 4 waves) against each other: predictions to 1e-6 of
+    their range, every parameter gradient to 1e-5, and the bf16x3 kernels bit-reproducible."""
+    ops = amd.ops
+    torch.manual_seed(n)
+    k_in, H = 32, 128
+    params = [(torch.randn(H, k_in, device="cuda") * 0.2, torch.randn(H, device="cuda") * 0.1),
+              (torch.randn(H, H, device="cuda") * 0.1, torch.randn(H, device="cuda") * 0.1),
+              (torch.randn(1, H, device="cuda") * 0.1, torch.randn(1, device="cuda") * 0.1)]
+    # rows with a pre-activation within 1e-4 of a ReLU kink are dropped: there two correct f32
+    # evaluations may disagree on the mask, which moves a whole row of the gradient sums
+    # (tools/fuzz.py and the kink regression seeds cover that case)
+    xs = torch.rand(k_in, n + n // 4 + 64, device="cuda") * 2 - 1
+    (w1, b1), (w2, b2), _ = [(w_.double(), b_.double()) for w_, b_ in params]
+    z1 = w1 @ xs.double() + b1[:, None]
+    z2 = w2 @ z1.clamp_min(0) + b2[:, None]
+    keep = (torch.minimum(z1.abs().amin(dim=0), z2.abs().amin(dim=0)) > 1e-4).nonzero().flatten()[:n]
+    assert keep.numel() == n
+    x = xs[:, keep].contiguous()
+    t = torch.rand(n, 1, device="cuda")
+    out = {}
+    try:
+        for mode in (0, 1, 2, 1):
+            _set_option("mlp_x3", mode)
+            grads = [(torch.zeros_like(w_), torch.zeros_like(b_)) for w_, b_ in params]
+            dx, y, loss = torch.empty_like(x), torch.empty(n, 1, device="cuda"), torch.zeros(1, device="cuda")
+            ops.tiny_mlp_train(x, t, params, grads, loss, d_x=dx, y=y, overwrite=True)
+            res = dict(y=y, loss=loss, g=[g_ for wb in grads for g_ in wb], dx=dx,
+                       fwd=ops.tiny_mlp_forward(x, params))
+            if mode in out:  # second run of the same kernel: same bits
+                assert torch.equal(res["y"], out[mode]["y"]) and torch.equal(res["dx"], out[mode]["dx"])
+                assert all(torch.equal(u, v) for u, v in zip(res["g"], out[mode]["g"]))
+            out[mode] = res
+    finally:
+        _set_option("mlp_x3", 1)
+    ref = out[0]
+    for mode in (1, 2):
+        r = out[mode]
+        assert torch.equal(r["fwd"], r["y"])  # inference and training kernels: same forward
+        assert float((r["y"] - ref["y"]).abs().max()) <= 1e-6 * float(ref["y"].abs().max())
+        assert abs(float(r["loss"]) - float(ref["loss"])) <= 1e-6 * float(ref["loss"])
+        for u, v in zip(r["g"], ref["g"]):
+            assert_close(u.cpu().numpy(), v.cpu().numpy(), REL_TOL, "gradient")
+        assert_close(r["dx"].cpu().numpy(), ref["dx"].cpu().numpy(), REL_TOL, "dx")
 
 
 def test_overlapped_decoder_gives_up_instead_of_hanging(amd):

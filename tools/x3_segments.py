@@ -72,7 +72,7 @@ def main():
     waves = 8 // mode
     p = prof.cpu().reshape(blocks, 8, 32).double()[:, :waves]
     tiles = n / 32 / blocks
-    names = ["S7 dW1+dx+stage (-> B0)", "S1 layer 1 (-> B1)", "S2 layer 2 (-> B2)", "S5 y, dz2 (-> B3)", "S6 dW2+dz1 (-> B4)"]
+    names = ["S7 dx + next layer 1 (-> B0)", "(unused)", "S2 layer 2 (-> B2)", "S5 y, dz2, dW2 (-> B3)", "S6 dz1, dW1 (-> B4)"]
     q = p.mean(dim=(0, 1)) / tiles
     tot = float(q[:10].sum())
     print(f"{'forward' if fwd else 'train'} mode {mode} ({waves} waves): {ms * 1e3:.1f} us with counters; {tiles:.0f} tiles per workgroup; "
