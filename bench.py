@@ -27,6 +27,25 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # exact-f32 matrix rate (no xf32 on gfx950)
+# The 128-wide decoder and the SIREN chain multiply on the bf16 pipe with operands split exactly into
+# three bf16 terms: six bf16 MFMAs per f32-accurate product (csrc/bf16x3.h).  Their ceiling in
+# ALGORITHMIC (f32) flops is the dense bf16 peak (16 x the f32 MFMA rate, MI355X_MICROARCH.md) / 6.
+MFMA_BF16_PEAK_TF = 16 * MFMA_F32_PEAK_TF
+MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6
+
+
+def mfma_roof(step, achieved_tf):
+    """Roofline entry of a matrix-bound phase: which pipe the model's products run on."""
+    x3 = bool(getattr(step, "use_chain", False)) or (
+        bool(getattr(step, "use_tiny", False)) and step.layers[0].weight.shape[0] == 128
+        and step.layers[0].weight.shape[1] <= 32)
+    peak = MFMA_X3_PEAK_TF if x3 else MFMA_F32_PEAK_TF
+    roof = dict(bound="mfma", achieved=achieved_tf, peak=peak, unit="TFLOP/s",
+                pipe=("bf16 MFMA, 6 products of exact three-term operands per f32 product: "
+                      "peak = 2517 TF bf16 dense / 6") if x3 else "f32 MFMA")
+    if x3:
+        roof["vs_f32_mfma_peak"] = achieved_tf / MFMA_F32_PEAK_TF
+    return roof
 
 WORKLOADS = {
     "cfg4": dict(shape=(256, 256, 256), model="hash", finest=16 * 1.4 ** 15, hidden=128,
@@ -196,9 +215,10 @@ def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
     dominant = max((p for p in phases if p in pm), key=lambda p: phases[p])
     bound, amount = pm[dominant]
     sec = phases[dominant] * 1e-3
-    roof = dict(bound=bound, achieved=amount / sec / (1e9 if bound == "hbm" else 1e12),
-                peak=HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF,
-                unit="GB/s" if bound == "hbm" else "TFLOP/s")
+    if bound == "hbm":
+        roof = dict(bound="hbm", achieved=amount / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    else:
+        roof = mfma_roof(step, amount / sec / 1e12)
     roof.update(frac=roof["achieved"] / roof["peak"],
                 traffic=pmc_traffic(args.workload + "_predict", dominant), kernel=dominant,
                 ms_per_launch=phases[dominant])
@@ -381,8 +401,7 @@ def main():
     if bound == "hbm":
         roof = dict(bound="hbm", achieved=amount / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
     else:
-        roof = dict(bound="mfma", achieved=amount / sec / 1e12, peak=MFMA_F32_PEAK_TF,
-                    unit="TFLOP/s")
+        roof = mfma_roof(step, amount / sec / 1e12)
     roof.update(frac=roof["achieved"] / roof["peak"], traffic=pmc_traffic(args.workload, dominant),
                 kernel=dominant, ms_per_launch=phases[dominant])
     result = {

@@ -25,6 +25,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          # hardware float atomics (global_atomic_add_f32 / ds_add_f32), never a CAS loop
          "-munsafe-fp-atomics",
          "-Wno-pass-failed", "-I" + os.path.join(ROOT, "include")]
+# per-source extras.  siren_chain.hip: hipcc's SLP vectoriser turns the operand split's subtractions
+# into v_pk_add_f32, the slower form beside bf16 MFMAs (MI355X_MICROARCH.md, packed f32 VALU):
+# config-3 step 13.25 -> 12.58 ms without it (the explicitly packed sincos stays: 12.72 unpacked).
+# The decoder kernels measured the same either way.
+EXTRA_FLAGS = {"siren_chain.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -44,15 +49,15 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libmri_inr.so; returns its path."""
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "hashgrid_common.h"), os.path.join(CSRC, "device_math.h"),
-               os.path.join(ROOT, "include", "mri_inr.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "hashgrid_common.h", "device_math.h", "bf16x3.h",
+                                               "mlp_fused.h")] + [os.path.join(ROOT, "include", "mri_inr.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+            cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE,

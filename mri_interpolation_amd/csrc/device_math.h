@@ -38,6 +38,11 @@ __device__ __forceinline__ void sincos_fast(float u, float* s_out, float* c_out)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sincos_fast2(float u0, float u1, float* s0, float* c0, float* s1,
                                              float* c1) {
+#ifdef MRI_SCALAR_SINCOS  // A/B builds: beside bf16 MFMAs packed f32 VALU can be the slower form
+  sincos_fast(u0, s0, c0);
+  sincos_fast(u1, s1, c1);
+  return;
+#endif
   if (fabsf(u0) > 8192.0f || fabsf(u1) > 8192.0f) {
     sincos_fast(u0, s0, c0);
     sincos_fast(u1, s1, c1);
