@@ -16,6 +16,9 @@ for w in cfg4 cfg3; do
   bash tools/gpu_pmc.sh ${w}_fetch "FETCH_SIZE" --workload $w --steps 6 --warmup 2 > $o/pmc_${w}_fetch.log 2>&1
   bash tools/gpu_pmc.sh ${w}_write "WRITE_SIZE" --workload $w --steps 6 --warmup 2 > $o/pmc_${w}_write.log 2>&1
 done
-bash tools/gpu_pmc.sh cfg4_sq "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" --steps 6 --warmup 2 > $o/pmc_cfg4_sq.log 2>&1
+for w in cfg4 cfg3; do
+  bash tools/gpu_pmc.sh ${w}_sq "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" --workload $w --steps 6 --warmup 2 > $o/pmc_${w}_sq.log 2>&1
+done
+bash tools/gpu_pmc.sh cfg4_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES" --steps 6 --warmup 2 > $o/pmc_cfg4_lds.log 2>&1
 grep -h "^siren\|^tiny\|^hash\|^bin\|^dense\|^adam" $o/pmc_*.log | cut -c1-300
 cat $o/bench_cfg4.json | cut -c1-1500
