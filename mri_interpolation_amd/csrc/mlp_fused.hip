@@ -12,8 +12,9 @@
 //        x tile (64 x K_in), h1 (64 x H), h2 (64 x H)   h2 becomes dz2 in place, h1 becomes dz1
 //   VGPR dW2 / dW1 accumulators (f32 MFMA C registers) live across ALL tiles of the workgroup;
 //        bias and last-layer gradients accumulate in plain registers.
-//   All seven products of a tile run on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact f32: the
-//   1e-5 parity target rules out bf16, and gfx950 has no xf32), fragments read from LDS images
+//   All seven products of a tile run on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact f32; the
+//   128-wide decoder has since moved to the bf16 pipe with three-term operands, mlp_x3.hip: these
+//   kernels serve H = 64, option mlp_x3 = 0 and the overlapped form), fragments read from LDS images
 //   whose leading dimensions (H+1, K_in+1) make both orientations of every operand
 //   conflict-free, so W2 and the activations are stored once and read as W2 and W2^T.
 //   Input features arrive feature-major (K_in, n) straight from the hash-grid kernel and the

@@ -10,9 +10,9 @@
 //   siren_forward_kernel   one persistent 512-thread workgroup per CU walks row tiles; per tile the
 //     first layer (K = dim_in) runs on the VALU straight into an LDS activation image, every
 //     H x H layer multiplies that image (A operand, ds_read_b128) with the layer's weights
-//     streamed from L2 in 32-deep chunks by LDS-DMA (global_load_lds_dwordx4, double buffered,
+//     streamed from L2 in 16-deep chunks by LDS-DMA (global_load_lds_dwordx4, double buffered,
 //     XOR-swizzled on the source side so that the B-operand ds_read_b128 are conflict-free) on
-//     v_mfma_f32_32x32x2_f32 (exact f32: the 1e-5 parity target rules out bf16), applies
+//     the bf16 matrix pipe with three-term operands (f32-accurate, see MRI_SIREN_X3 below), applies
 //     bias / w0 / sincos in registers and overwrites the image; the 1-wide head is a wave
 //     reduction over the image.  For training the activation a_l = sin(.) and its derivative
 //     w0 cos(.) leave for HBM once (the backward kernels need them); they are dripped out of
