@@ -37,7 +37,7 @@ MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6
 def mfma_roof(step, achieved_tf):
     """Roofline entry of a matrix-bound phase: which pipe the model's products run on."""
     x3 = bool(getattr(step, "use_chain", False)) or (
-        bool(getattr(step, "use_tiny", False)) and step.layers[0].weight.shape[0] == 128
+        bool(getattr(step, "use_tiny", False)) and step.layers[0].weight.shape[0] in (64, 128)
         and step.layers[0].weight.shape[1] <= 32)
     peak = MFMA_X3_PEAK_TF if x3 else MFMA_F32_PEAK_TF
     roof = dict(bound="mfma", achieved=achieved_tf, peak=peak, unit="TFLOP/s",

@@ -69,8 +69,8 @@ const char* mri_version(void);
 const char* mri_last_error(void);
 /* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level" n,
  * "bwd_dense_max_parts" n, "bwd_dense_blocks" n, "bwd_fuse_dense" 0/1, "fwd_pair" 0/1,
- * "mlp_stagger" 0..8, "mlp_x3" 0/1/2: which kernel serves the 128-wide decoder -- 1 (default) the
- * bf16-pipe kernel with exact three-term operands, 2 its four-wave form, 0 the f32-MFMA kernel);
+ * "mlp_stagger" 0..8, "mlp_x3" 0/1/2: which kernel serves the decoder -- 1 (default) the bf16-pipe
+ * kernel with exact three-term operands, 2 its four-wave form (128-wide), 0 the f32-MFMA kernels);
  * results stay within fp32 summation-order noise. */
 int mri_set_option(const char* name, int32_t value);
 
@@ -180,9 +180,9 @@ int mri_frequency_backward(const float* x, int64_t ldx, const float* d_out, int6
  * The decoder of BASELINE configs 2/4/5: k_in -> hidden -> hidden -> 1, ReLU on the hidden
  * layers, linear output (reference config/hash_config.json "network"; module form
  * models.py:46-56 / 730-744 with ReLU, no BatchNorm).  ONE persistent kernel per call:
- * activations never leave the CU; hidden 128: weights in registers, products on the bf16 matrix
+ * activations never leave the CU; k_in <= 32: weights in registers, products on the bf16 matrix
  * pipe with every f32 operand split exactly into three bf16 terms (f32-accurate, csrc/bf16x3.h);
- * hidden 64: weights resident in LDS, products on the f32 MFMA.
+ * hidden 64 with 32 < k_in <= 64: weights resident in LDS, products on the f32 MFMA.
  *   x        (k_in, n) FEATURE-MAJOR input features (the layout mri_hashgrid_forward writes)
  *   w1 (hidden, k_in), w2 (hidden, hidden), w3 (1, hidden) row-major as nn.Linear stores them
  * mri_tiny_mlp_supported: 1 if (k_in, hidden, dim_out) has a fused kernel

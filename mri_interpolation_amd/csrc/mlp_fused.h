@@ -31,11 +31,11 @@ struct FusedArgs {
 // slab layout (floats): dW1 [H*k_in] | db1 [H] | dW2 [H*H] | db2 [H] | dW3 [H] | db3 [1] | loss [1]
 __host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + H + H * H + H + H + 2; }
 
-// mlp_x3.hip: 32 -> 128 -> 128 -> 1 on the bf16 matrix pipe (three-term split operands), one
+// mlp_x3.hip: k_in <= 32 -> 128 -> 128 -> 1 and -> 64 -> 64 -> 1 on the bf16 matrix pipe (three-term split operands), one
 // 512-thread workgroup per CU, one slab per workgroup (train).  `blocks` <= x3_max_blocks(n).
 bool x3_supported(int k_in, int hidden);
 bool x3_addressable(const FusedArgs& a);  // 32-bit lane offsets inside x / dx
 int x3_blocks(int64_t n);
-int launch_tiny_mlp_x3(const FusedArgs& a, bool train, int blocks, hipStream_t st);
+int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st);
 
 }  // namespace mri

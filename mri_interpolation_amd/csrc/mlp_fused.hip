@@ -954,7 +954,7 @@ bool use_x3(const FusedArgs& a, int hidden) {
 }
 
 int dispatch(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
-  if (use_x3(a, hidden)) return launch_tiny_mlp_x3(a, train, blocks, st);
+  if (use_x3(a, hidden)) return launch_tiny_mlp_x3(a, hidden, train, blocks, st);
   if (hidden == 128) {  // tiny_mlp_kernel<128, ...> (one 4-wave team) is not instantiated: 7 % slower
     if (train)
       hipLaunchKernelGGL((tiny_mlp_team_kernel<128, 32, true>), dim3(blocks),

@@ -1,6 +1,7 @@
 // Fused tiny-MLP (ReLU) forward + MSE + backward on the bf16 matrix pipe, f32-accurate ("bf16x3",
-// see bf16x3.h): the decoder of BASELINE configs 4 / 5 (32 -> 128 -> 128 -> 1; reference
-// models.py:46-66 training_step, 730-744 HashMLP decoder) in one persistent kernel per step.
+// see bf16x3.h): the decoder of BASELINE configs 2 / 4 / 5 (k_in <= 32 -> H -> H -> 1, H = 128 or 64;
+// reference models.py:46-66 training_step, 730-744 HashMLP decoder) in one persistent kernel per step.
+// The description below is for H = 128; the kernel's head comment has the H = 64 mapping.
 //
 // Same contract as mlp_fused.hip's f32-MFMA kernels (FusedArgs, one slab of partial gradients per
 // workgroup, summed in a fixed order by slab_reduce_kernel), different machine mapping.  Every f32
@@ -143,11 +144,21 @@ __device__ __forceinline__ float sum_groups(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-template <bool TRAIN, int U>
+template <bool TRAIN, int U, int H>
 __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a) {
   // U = strips of 16 hidden units per wave: 1 -> 8 waves (two per SIMD, 256 registers each),
-  // 2 -> 4 waves (one per SIMD, 512 registers; every activation fragment feeds two strips)
-  constexpr int H = kX3H, WAVES = 8 / U, THREADS = kX3Threads / U;
+  // 2 -> 4 waves (one per SIMD, 512 registers; every activation fragment feeds two strips).
+  // H = 128: wave w owns strip w (U = 1) for both 16-row halves of the tile.  H = 64 (U = 1): four
+  // strips; wave w owns strip w & 3 for the tile's row half w >> 2 (TL = 1 half per wave), on the same
+  // 256-byte image rows (units 64..127 unused), so every address and swizzle below is shared.  The
+  // batch-contracting products (dW2, dW1) then run over the wave's OWN 16 rows with the other half of
+  // the 32-deep step zeroed (its partner's rows are not behind a barrier); the two partial sums of a
+  // strip meet in the epilogue.
+  static_assert((H == 128) || (H == 64 && U == 1), "hidden width");
+  constexpr int WAVES = 8 / U, THREADS = kX3Threads / U;
+  constexpr int KS = H / 32, KT = H / 16;          // 32-deep contraction steps / 16-unit tiles over the hidden units
+  constexpr int TL = H == 128 ? 2 : 1;             // row halves of the tile a wave works on
+  constexpr int YS = H == 128 ? WAVES : 4;         // y shares per row
   constexpr int IMG = kImgBytes, IMG32 = kImg32Bytes;
   __shared__ X3Smem sm;
   X3P_START
@@ -155,19 +166,23 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g = lane >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto unit0 = [&](int u) { return 16 * (U * w + u); };  // first hidden unit of the wave's strip u
+  const int th = H == 128 ? 0 : w >> 2;            // first row half of this wave
+  auto strip = [&](int u) { return H == 128 ? U * w + u : (w & 3); };
+  auto unit0 = [&](int u) { return 16 * strip(u); };  // first hidden unit of the wave's strip u
+  const int yslot = H == 128 ? w : (w & 3);
+  const bool y_owner = yslot == 0;                 // the wave(s) that store y and sum the loss
 
   // ---- resident weight fragments (A operands: row = unit unit0(u) + li, 8 g + j = contraction)
   // W2's two larger terms stay in registers (64 per strip, both orientations); its smallest term, used
   // by one MFMA in six, is read from an LDS image: all three in registers left no room for the fragment
   // double buffers, and a spilled fragment's reload waits behind every load in flight (vmcnt)
-  u32x4 w2f_h[U][4], w2f_m[U][4], w2t_h[U][4], w2t_m[U][4];
+  u32x4 w2f_h[U][KS], w2f_m[U][KS], w2t_h[U][KS], w2t_m[U][KS];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = unit0(u) + li;
     float v[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = a.w2[n * H + 32 * s + 8 * g + j];
       const Frag f = split8(v);
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     }
     if (TRAIN) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {  // dz1 = dz2 W2: row = input unit n of layer 2, contraction = its output unit
+      for (int s = 0; s < KS; ++s) {  // dz1 = dz2 W2: row = input unit n of layer 2, contraction = its output unit
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = a.w2[(32 * s + 8 * g + j) * H + n];
         const Frag f = split8(v);
@@ -183,8 +198,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       }
     }
   }
-  for (int e = tid; e < H * 32; e += THREADS) {  // W2's third term: row = output unit, 4 inputs per store
-    const int n = e >> 5, c4 = e & 31;
+  for (int e = tid; e < H * (H / 4); e += THREADS) {  // W2's third term: row = output unit, 4 inputs per store
+    const int n = e / (H / 4), c4 = e % (H / 4);
     const float4 v = *reinterpret_cast<const float4*>(a.w2 + n * H + 4 * c4);
     uint32_t h0, m0, l0, h1, m1, l1;
     split2(v.x, v.y, h0, m0, l0);
@@ -205,12 +220,12 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   if (tid < H) sm.b1[tid] = a.b1[tid], sm.b2[tid] = a.b2[tid], sm.w3[tid] = a.w3[tid];
   const float b3 = a.b3[0];
 
-  f32x4 g_w2[U][8], g_w1[U][2];
+  f32x4 g_w2[U][KT], g_w1[U][2];
   float g_b1[U][4], g_b2[U][4], g_w3[U][4], g_b3 = 0.f, loss = 0.f;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) g_w2[u][q] = zero4;
+    for (int q = 0; q < KT; ++q) g_w2[u][q] = zero4;
     g_w1[u][0] = g_w1[u][1] = zero4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) g_b1[u][r] = g_b2[u][r] = g_w3[u][r] = 0.f;
@@ -229,7 +244,20 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   int a_out[U];                                                                        // + 4096 t
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    a_out[u] = 256 * li + 8 * (g & 1) + 16 * ((g >> 1) ^ (swl & 1)) + ((32 * (U * w + u)) ^ (16 * (swl & 14)));
+    a_out[u] = 256 * li + 8 * (g & 1) + 16 * ((g >> 1) ^ (swl & 1)) + ((32 * strip(u)) ^ (16 * (swl & 14)));
+  // dz2 / dz1 columns of the wave's strip as the A operand of a batch-contracting product: every row
+  // of the tile it wrote itself -- all 32 (H = 128), or its half with the other half of the step zero
+  auto own_tr = [&](const char* img, int off) {
+    if (H == 128) return ld_tr<IMG, 4096>(img, off);
+    Frag f;
+    const u32x2 x0 = lds_read_tr(img + off + 4096 * th), x1 = lds_read_tr(img + IMG + off + 4096 * th),
+                x2 = lds_read_tr(img + 2 * IMG + off + 4096 * th);
+    const uint32_t keep_lo = th ? 0u : 0xffffffffu, keep_hi = ~keep_lo;
+    f.h = u32x4{x0[0] & keep_lo, x0[1] & keep_lo, x0[0] & keep_hi, x0[1] & keep_hi};
+    f.m = u32x4{x1[0] & keep_lo, x1[1] & keep_lo, x1[0] & keep_hi, x1[1] & keep_hi};
+    f.l = u32x4{x2[0] & keep_lo, x2[1] & keep_lo, x2[0] & keep_hi, x2[1] & keep_hi};
+    return f;
+  };
   char* const smb = reinterpret_cast<char*>(&sm);
   char* const i_h1 = smb + offsetof(X3Smem, h1);
   char* const i_z2 = smb + offsetof(X3Smem, z2);
@@ -281,30 +309,30 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   uint32_t mask1 = 0;
   auto layer1 = [&](int xbuf) {
     const char* const i_x = smb + offsetof(X3Smem, x) + xbuf * (3 * IMG32);
-    Frag w1f[U], xb[2];
+    Frag w1f[U], xb[TL];
 #pragma unroll
-    for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * (U * w + u));
-    xb[0] = ld_row<IMG32>(i_x, a_row32);
-    xb[1] = ld_row<IMG32>(i_x, a_row32 + 1024);
+    for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * strip(u));
+#pragma unroll
+    for (int tt = 0; tt < TL; ++tt) xb[tt] = ld_row<IMG32>(i_x, a_row32 + 1024 * (th + tt));
     f32x4 bias[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) bias[u] = *reinterpret_cast<const f32x4*>(&sm.b1[unit0(u) + 4 * g]);
     X3_PIN
     mask1 = 0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int tt = 0; tt < TL; ++tt) {
       f32x4 c[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) c[u] = mma6(w1f[u], xb[t], zero4);
+      for (int u = 0; u < U; ++u) c[u] = mma6(w1f[u], xb[tt], zero4);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         float h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           h[r] = fmaxf(c[u][r] + bias[u][r], 0.f);
-          mask1 |= (h[r] > 0.f ? 1u : 0u) << (8 * u + 4 * t + r);
+          mask1 |= (h[r] > 0.f ? 1u : 0u) << (8 * u + 4 * tt + r);
         }
-        st4(i_h1, a_out[u] + 4096 * t, h);
+        st4(i_h1, a_out[u] + 4096 * (th + tt), h);
       }
     }
   };
@@ -342,15 +370,15 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     if (!TRAIN) stage_next();
     X3P_SYNC(0)  // B0: h1 of this tile complete (and, inference, x of the next staged)
     // ---- S2: h2 = relu(h1 W2^T + b2); this wave's share of y ---------------------------------------
-    float h2[U][2][4];
+    float h2[U][TL][4];
     {
       Frag hb[2];
-      u32x4 wl[U][4];  // W2's third term, rows of this wave's strips
+      u32x4 wl[U][KS];  // W2's third term, rows of this wave's strips
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wl[u][s] = lds_read_b128(i_w2l + (a_row ^ (64 * s)) + 4096 * (U * w + u));
-      hb[0] = ld_row<IMG>(i_h1, a_row);
+        for (int s = 0; s < KS; ++s) wl[u][s] = lds_read_b128(i_w2l + (a_row ^ (64 * s)) + 4096 * strip(u));
+      hb[0] = ld_row<IMG>(i_h1, a_row + 4096 * th);
       f32x4 bias[U], w3v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -358,14 +386,15 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         w3v[u] = *reinterpret_cast<const f32x4*>(&sm.w3[unit0(u) + 4 * g]);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int tt = 0; tt < TL; ++tt) {
         f32x4 c[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) c[u] = zero4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int i = 4 * t + s;
-          if (i < 7) hb[(i + 1) & 1] = ld_row<IMG>(i_h1, (a_row ^ (64 * ((s + 1) & 3))) + 4096 * ((i + 1) >> 2));
+        for (int s = 0; s < KS; ++s) {
+          const int i = KS * tt + s;  // next fragment: step (s + 1) % KS of half (i + 1) / KS
+          if (i + 1 < KS * TL)
+            hb[(i + 1) & 1] = ld_row<IMG>(i_h1, (a_row ^ (64 * ((s + 1) % KS))) + 4096 * (th + (i + 1) / KS));
           X3_PIN
 #pragma unroll
           for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2f_h[u][s], w2f_m[u][s], wl[u][s]}, hb[i & 1], c[u]);
@@ -376,39 +405,40 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            h2[u][t][r] = fmaxf(c[u][r] + bias[u][r], 0.f);
-            yp += w3v[u][r] * h2[u][t][r];
+            h2[u][tt][r] = fmaxf(c[u][r] + bias[u][r], 0.f);
+            yp += w3v[u][r] * h2[u][tt][r];
           }
         yp = sum_groups(yp);
-        if (g == 0) sm.ypart[w][16 * t + li] = yp;
+        if (g == 0) sm.ypart[yslot][16 * (th + tt) + li] = yp;
       }
     }
     X3P_SYNC(2)  // B2
     // ---- S5: prediction, loss, dy (every lane for its own row), dz2 of this wave's units -----------
     {
-      float yq[2][WAVES], tg[2] = {0.f, 0.f};  // all LDS reads first: no read -> use -> read chains
+      float yq[TL][YS], tg[TL];  // all LDS reads first: no read -> use -> read chains
       f32x4 w3v[U];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int tt = 0; tt < TL; ++tt) {
 #pragma unroll
-        for (int q = 0; q < WAVES; ++q) yq[t][q] = sm.ypart[q][16 * t + li];
-        if (TRAIN) tg[t] = sm.tgt[buf][16 * t + li];
+        for (int q = 0; q < YS; ++q) yq[tt][q] = sm.ypart[q][16 * (th + tt) + li];
+        tg[tt] = TRAIN ? sm.tgt[buf][16 * (th + tt) + li] : 0.f;
       }
       if (TRAIN) {
 #pragma unroll
         for (int u = 0; u < U; ++u) w3v[u] = *reinterpret_cast<const f32x4*>(&sm.w3[unit0(u) + 4 * g]);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int tt = 0; tt < TL; ++tt) {
+        const int t = th + tt;
         float y = b3;
 #pragma unroll
-        for (int q = 0; q < WAVES; ++q) y += yq[t][q];
+        for (int q = 0; q < YS; ++q) y += yq[tt][q];
         const bool live = 16 * t + li < a.n - m0;
-        if (w == 0 && g == 0 && live && a.y) (a.y + m0)[16 * t + li] = y;
+        if (y_owner && g == 0 && live && a.y) (a.y + m0)[16 * t + li] = y;
         if (TRAIN) {
-          const float diff = live ? y - tg[t] : 0.f;
+          const float diff = live ? y - tg[tt] : 0.f;
           const float d = diff * a.grad_scale;
-          if (w == 0 && g == 0) {
+          if (y_owner && g == 0) {
             loss += diff * diff;
             g_b3 += d;
           }
@@ -417,9 +447,9 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
             float z[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              g_w3[u][r] += d * h2[u][t][r];
+              g_w3[u][r] += d * h2[u][tt][r];
               const float dw = d * w3v[u][r];
-              z[r] = h2[u][t][r] > 0.f ? dw : 0.f;
+              z[r] = h2[u][tt][r] > 0.f ? dw : 0.f;
               g_b2[u][r] += z[r];
             }
             st4(i_z2, a_out[u] + 4096 * t, z);
@@ -438,10 +468,10 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       Frag za[U], hk[2];
       hk[0] = ld_tr<IMG, 4096>(i_h1, a_tr);
 #pragma unroll
-      for (int u = 0; u < U; ++u) za[u] = ld_tr<IMG, 4096>(i_z2, a_tr ^ (32 * (U * w + u)));
+      for (int u = 0; u < U; ++u) za[u] = own_tr(i_z2, a_tr ^ (32 * strip(u)));
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-        if (kt < 7) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
         X3_PIN
 #pragma unroll
         for (int u = 0; u < U; ++u) g_w2[u][kt] = mma6(za[u], hk[kt & 1], g_w2[u][kt]);
@@ -454,27 +484,28 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       Frag zb[2];
       // W2^T's third term: lane (li, g) = input unit unit0 + li, output units 32 s + 8 g + j: transposed
       // read of rows 32 s + 8 g + q (+ 4) of the image; their swizzles differ by sw(q + 4) = sw(q) ^ 9
-      u32x4 wl[U][4];
+      u32x4 wl[U][KS];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int a0 = 2048 * g + 256 * q4 + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (sw(q4) & 1)) +
-                       ((32 * (U * w + u)) ^ (16 * (sw(q4) & 14)));
+                       ((32 * strip(u)) ^ (16 * (sw(q4) & 14)));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
           const u32x2 lo = lds_read_tr(i_w2l + a0 + 8192 * s), hi = lds_read_tr(i_w2l + (a0 ^ 144) + 8192 * s + 1024);
           wl[u][s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
-      zb[0] = ld_row<IMG>(i_z2, a_row);
+      zb[0] = ld_row<IMG>(i_z2, a_row + 4096 * th);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int tt = 0; tt < TL; ++tt) {
         f32x4 c[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) c[u] = zero4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int i = 4 * t + s;
-          if (i < 7) zb[(i + 1) & 1] = ld_row<IMG>(i_z2, (a_row ^ (64 * ((s + 1) & 3))) + 4096 * ((i + 1) >> 2));
+        for (int s = 0; s < KS; ++s) {
+          const int i = KS * tt + s;
+          if (i + 1 < KS * TL)
+            zb[(i + 1) & 1] = ld_row<IMG>(i_z2, (a_row ^ (64 * ((s + 1) % KS))) + 4096 * (th + (i + 1) / KS));
           X3_PIN
 #pragma unroll
           for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2t_h[u][s], w2t_m[u][s], wl[u][s]}, zb[i & 1], c[u]);
@@ -485,10 +516,10 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
           float z[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            z[r] = ((mask1 >> (8 * u + 4 * t + r)) & 1u) ? c[u][r] : 0.f;
+            z[r] = ((mask1 >> (8 * u + 4 * tt + r)) & 1u) ? c[u][r] : 0.f;
             g_b1[u][r] += z[r];
           }
-          st4(i_z1, a_out[u] + 4096 * t, z);
+          st4(i_z1, a_out[u] + 4096 * (th + tt), z);
         }
       }
     }
@@ -497,7 +528,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       const Frag xk = ld_tr<IMG32, 1024>(i_x, a_tr32), x1 = ld_tr<IMG32, 1024>(i_x, a_tr32 ^ 32);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const Frag za = ld_tr<IMG, 4096>(i_z1, a_tr ^ (32 * (U * w + u)));
+        const Frag za = own_tr(i_z1, a_tr ^ (32 * strip(u)));
         g_w1[u][0] = mma6(za, xk, g_w1[u][0]);
         g_w1[u][1] = mma6(za, x1, g_w1[u][1]);
       }
@@ -524,8 +555,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       };
       wa[0] = w1t_frag(0), zc[0] = ld_row<IMG>(i_z1, a_row + 4096 * bt);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s < 3) {
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
           wa[(s + 1) & 1] = w1t_frag(s + 1);
           zc[(s + 1) & 1] = ld_row<IMG>(i_z1, (a_row ^ (64 * (s + 1))) + 4096 * bt);
         }
@@ -550,14 +581,6 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     return;
   }
 
-  // ---- this workgroup's slab: every element of dW2 / dW1 has exactly one owner lane ----------------
-  float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
-  float* p_w1 = slab;
-  float* p_b1 = p_w1 + H * a.k_in;
-  float* p_w2 = p_b1 + H;
-  float* p_b2 = p_w2 + H * H;
-  float* p_w3 = p_b2 + H;
-  float* p_b3 = p_w3 + H;
   // per-unit sums: the 16 lanes li of a group hold the 16 (+16) rows' shares, in a fixed order
   auto rows_sum = [](float v) {
     v += __shfl_xor(v, 1, 64);
@@ -566,11 +589,68 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     v += __shfl_xor(v, 8, 64);
     return v;
   };
+  float s_b1[U][4], s_b2[U][4], s_w3[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s_b1[u][r] = rows_sum(g_b1[u][r]), s_b2[u][r] = rows_sum(g_b2[u][r]), s_w3[u][r] = rows_sum(g_w3[u][r]);
+    }
+  float s_b3 = rows_sum(g_b3), s_loss = rows_sum(loss);  // only the y owners' lanes g == 0 hold shares
+  if (H == 64) {
+    // the two waves of a strip (row halves 0 and 1) each hold a partial sum of everything: wave w + 4
+    // hands its values to wave w through LDS (the images are dead), which adds them in a fixed order
+    constexpr int PER = 4 * KT + 8 + 12 + 2;  // floats per lane
+    float* x = reinterpret_cast<float*>(smb);
+    __syncthreads();
+    float* mine = x + ((w & 3) * 64 + lane) * PER;
+    if (w >= 4) {
+      int o = 0;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[o++] = g_w2[0][kt][r];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[o++] = g_w1[0][kt][r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[o++] = s_b1[0][r], mine[o++] = s_b2[0][r], mine[o++] = s_w3[0][r];
+      mine[o++] = s_b3, mine[o++] = s_loss;
+    }
+    __syncthreads();
+    if (w >= 4) {
+      X3P_MARK(21)
+      X3P_END
+      return;
+    }
+    int o = 0;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g_w2[0][kt][r] += mine[o++];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g_w1[0][kt][r] += mine[o++];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_b1[0][r] += mine[o++], s_b2[0][r] += mine[o++], s_w3[0][r] += mine[o++];
+    s_b3 += mine[o++], s_loss += mine[o++];
+  }
+
+  // ---- this workgroup's slab: every element of dW2 / dW1 has exactly one owner lane ----------------
+  float* slab = a.partial + (int64_t)blockIdx.x * slab_floats(H, a.k_in);
+  float* p_w1 = slab;
+  float* p_b1 = p_w1 + H * a.k_in;
+  float* p_w2 = p_b1 + H;
+  float* p_b2 = p_w2 + H * H;
+  float* p_w3 = p_b2 + H;
+  float* p_b3 = p_w3 + H;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int n = unit0(u) + 4 * g;
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) p_w2[(n + r) * H + 16 * kt + li] = g_w2[u][kt][r];
 #pragma unroll
@@ -579,17 +659,12 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       for (int r = 0; r < 4; ++r)
         if (16 * kt + li < a.k_in) p_w1[(n + r) * a.k_in + 16 * kt + li] = g_w1[u][kt][r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float s1 = rows_sum(g_b1[u][r]), s2 = rows_sum(g_b2[u][r]), s3 = rows_sum(g_w3[u][r]);
-      if (li == 0) p_b1[n + r] = s1, p_b2[n + r] = s2, p_w3[n + r] = s3;
-    }
+    for (int r = 0; r < 4; ++r)
+      if (li == 0) p_b1[n + r] = s_b1[u][r], p_b2[n + r] = s_b2[u][r], p_w3[n + r] = s_w3[u][r];
   }
-  if (w == 0) {  // only the lanes g == 0 hold non-zero shares
-    const float sb3 = rows_sum(g_b3), sl = rows_sum(loss);
-    if (lane == 0) {
-      p_b3[0] = sb3;
-      p_b3[1] = sl * a.inv_n;
-    }
+  if (w == 0 && lane == 0) {
+    p_b3[0] = s_b3;
+    p_b3[1] = s_loss * a.inv_n;
   }
   X3P_MARK(21)
   X3P_END
@@ -597,22 +672,26 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
 
 }  // namespace
 
-bool x3_supported(int k_in, int hidden) { return hidden == kX3H && k_in >= 1 && k_in <= 32; }
+bool x3_supported(int k_in, int hidden) { return (hidden == 128 || hidden == 64) && k_in >= 1 && k_in <= 32; }
 
 bool x3_addressable(const FusedArgs& a) { return (int64_t)a.k_in * a.ld < (1ll << 30); }
 
 int x3_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kX3Rows), 256); }
 
-int launch_tiny_mlp_x3(const FusedArgs& a, bool train, int blocks, hipStream_t st) {
-  const bool wide = options().mlp_x3 == 2;  // 4 waves of two strips (tools: A/B against 8 x 1)
-  if (train && wide)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
+  const bool wide = options().mlp_x3 == 2 && hidden == 128;  // 4 waves of two strips (tools: A/B against 8 x 1)
+  if (hidden == 64 && train)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+  else if (hidden == 64)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+  else if (train && wide)
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
   else if (train)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a);
   else if (wide)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 2>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
   else
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a);
   return check_launch("tiny_mlp_x3_kernel");
 }
 

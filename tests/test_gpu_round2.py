@@ -294,14 +294,14 @@ def _overlap_equals_sequential(amd, dim, n):
     steps[0].check_status()
 
 
-@pytest.mark.parametrize("n", [1 << 18, 70001, 33])
-def test_decoder_kernels_agree(amd, n):
-    """The three decoder kernels for 32 -> 128 -> 128 -> 1 (option mlp_x3: 0 = f32 MFMA team kernel,
-    1 = bf16x3 with 8 waves, 2 = bf16x3 with 4 waves) against each other: predictions to 1e-6 of
+@pytest.mark.parametrize("n,H,k_in", [(1 << 18, 128, 32), (70001, 128, 32), (33, 128, 32), (1 << 18, 64, 32),
+                                      (70001, 64, 19), (17, 64, 32), (5000, 128, 7)])
+def test_decoder_kernels_agree(amd, n, H, k_in):
+    """The decoder kernels for k_in -> H -> H -> 1 (option mlp_x3: 0 = f32 MFMA kernels, 1 = bf16x3
+    with 8 waves, 2 = bf16x3 with 4 waves (H = 128 only)) against each other: predictions to 1e-6 of
     their range, every parameter gradient to 1e-5, and the bf16x3 kernels bit-reproducible."""
     ops = amd.ops
     torch.manual_seed(n)
-    k_in, H = 32, 128
     params = [(torch.randn(H, k_in, device="cuda") * 0.2, torch.randn(H, device="cuda") * 0.1),
               (torch.randn(H, H, device="cuda") * 0.1, torch.randn(H, device="cuda") * 0.1),
               (torch.randn(1, H, device="cuda") * 0.1, torch.randn(1, device="cuda") * 0.1)]
@@ -318,7 +318,7 @@ def test_decoder_kernels_agree(amd, n):
     t = torch.rand(n, 1, device="cuda")
     out = {}
     try:
-        for mode in (0, 1, 2, 1):
+        for mode in ((0, 1, 2, 1) if H == 128 else (0, 1, 1)):
             _set_option("mlp_x3", mode)
             grads = [(torch.zeros_like(w_), torch.zeros_like(b_)) for w_, b_ in params]
             dx, y, loss = torch.empty_like(x), torch.empty(n, 1, device="cuda"), torch.zeros(1, device="cuda")
@@ -332,7 +332,7 @@ def test_decoder_kernels_agree(amd, n):
     finally:
         _set_option("mlp_x3", 1)
     ref = out[0]
-    for mode in (1, 2):
+    for mode in ((1, 2) if H == 128 else (1,)):
         r = out[mode]
         assert torch.equal(r["fwd"], r["y"])  # inference and training kernels: same forward
         assert float((r["y"] - ref["y"]).abs().max()) <= 1e-6 * float(ref["y"].abs().max())

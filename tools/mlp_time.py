@@ -7,7 +7,7 @@ from mri_interpolation_amd import _lib, ops
 _lib.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
 torch.manual_seed(0)
-k_in, H = 32, 128
+k_in, H = 32, int(sys.argv[2]) if len(sys.argv) > 2 else 128
 params = [(torch.randn(H, k_in, device="cuda") * 0.2, torch.randn(H, device="cuda") * 0.1),
           (torch.randn(H, H, device="cuda") * 0.1, torch.randn(H, device="cuda") * 0.1),
           (torch.randn(1, H, device="cuda") * 0.1, torch.randn(1, device="cuda") * 0.1)]
@@ -26,8 +26,8 @@ def run(x3):
     return tr, fw, [g.clone() for wb in grads for g in wb], dx.clone(), y.clone()
 def rel(u, v): return float((u - v).abs().max() / v.abs().max().clamp_min(1e-30))
 a = run(0)
-print("n %d  f32 team kernel: train %.4f ms  forward %.4f ms" % (n, a[0], a[1]), flush=True)
-for mode in (1, 2):
+print("H %d" % H, "n %d  f32 MFMA kernel: train %.4f ms  forward %.4f ms" % (n, a[0], a[1]), flush=True)
+for mode in ((1, 2) if H == 128 else (1,)):
     b = run(mode)
     print("bf16x3 (%d waves): train %.4f ms  forward %.4f ms | vs f32 kernel: y %.2e  dx %.2e  grads %s" % (
         8 // mode, b[0], b[1], rel(b[4], a[4]), rel(b[3], a[3]), " ".join("%.1e" % rel(u, v) for u, v in zip(b[2], a[2]))), flush=True)
