@@ -955,7 +955,9 @@ bool use_x3(const FusedArgs& a, int hidden) {
 
 int dispatch(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
   if (use_x3(a, hidden)) return launch_tiny_mlp_x3(a, hidden, train, blocks, st);
-  if (hidden == 128) {  // tiny_mlp_kernel<128, ...> (one 4-wave team) is not instantiated: 7 % slower
+  if (hidden == 128) {
+    MRI_REQUIRE((reinterpret_cast<uintptr_t>(a.w2) & 15) == 0,
+                "the f32-MFMA decoder kernel reads w2 in 16-byte pieces: w2 must be 16-byte aligned");  // tiny_mlp_kernel<128, ...> (one 4-wave team) is not instantiated: 7 % slower
     if (train)
       hipLaunchKernelGGL((tiny_mlp_team_kernel<128, 32, true>), dim3(blocks),
                          dim3(2 * kTeamThreads), 0, st, a);

@@ -200,10 +200,10 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   }
   for (int e = tid; e < H * (H / 4); e += THREADS) {  // W2's third term: row = output unit, 4 inputs per store
     const int n = e / (H / 4), c4 = e % (H / 4);
-    const float4 v = *reinterpret_cast<const float4*>(a.w2 + n * H + 4 * c4);
+    const float* v = a.w2 + n * H + 4 * c4;  // 4-byte loads: parameter views need not be 16-byte aligned
     uint32_t h0, m0, l0, h1, m1, l1;
-    split2(v.x, v.y, h0, m0, l0);
-    split2(v.z, v.w, h1, m1, l1);
+    split2(v[0], v[1], h0, m0, l0);
+    split2(v[2], v[3], h1, m1, l1);
     *reinterpret_cast<u32x2*>(sm.w2l + img_off(n, c4 >> 1) + 8 * (c4 & 1)) = u32x2{l0, l1};
   }
   for (int e = tid; e < H * 16; e += THREADS) {  // W1 image: row = hidden unit, pairs of input features
