@@ -1,0 +1,35 @@
+"""Does the order of a training batch matter to the lookup / table-gradient kernels?  Times both on a
+shuffled config-4 batch and on the same batch sorted in Morton (Z) order: python tools/sorted_batch_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mri_interpolation_amd import _lib, encoding, ops
+_lib.load()
+torch.manual_seed(0)
+n = 1 << 18
+enc = encoding.MultiResHashGrid(3, n_levels=16, n_features_per_level=2, log2_hashmap_size=19,
+                                base_resolution=16, finest_resolution=16 * 1.4 ** 15).cuda()
+idx = torch.randperm(256 ** 3, device="cuda")[:n]          # a 1/64 sample of the 256^3 voxels
+v = torch.stack([idx // 65536, (idx // 256) % 256, idx % 256], dim=1)
+x = (v.float() / 255.0).contiguous()
+def part(a):  # spread the low 8 bits of a
+    a = a.long()
+    a = (a | (a << 16)) & 0x0000FF0000FF
+    a = (a | (a << 8)) & 0x00F00F00F00F
+    a = (a | (a << 4)) & 0x0C30C30C30C3
+    a = (a | (a << 2)) & 0x249249249249
+    return a
+morton = part(v[:, 0]) | (part(v[:, 1]) << 1) | (part(v[:, 2]) << 2)
+xs = x[torch.argsort(morton)].contiguous()
+xr = x[torch.argsort(idx)].contiguous()                    # raster order
+d = torch.randn(enc.output_dim, n, device="cuda") * 1e-3
+def timed(fn, reps=30):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+out = torch.empty(enc.output_dim, n, device="cuda")
+g = torch.zeros_like(enc.table.data)
+for name, c in (("shuffled", x), ("raster  ", xr), ("morton  ", xs)):
+    f = timed(lambda: ops.hashgrid_forward(enc.desc, c, enc.table.data, out=out, feature_major=True))
+    b = timed(lambda: ops.hashgrid_backward(enc.desc, c, d, g, feature_major=True, method=2, overwrite=True))
+    print("%s: lookup %.4f ms   table gradient (count + scatter + accumulate on one stream) %.4f ms" % (name, f, b), flush=True)
