@@ -85,6 +85,11 @@ def test_every_entry_point_rejects_null_buffers_before_touching_the_device(lib):
         "mri_tiny_mlp_train": (None, None, 8, 32, 128) + (None,) * 6 + (1.0,) + (None,) * 10
                               + (0, None),
         "mri_adam_step": (None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None),
+        "mri_siren_forward": (None, 8, 3, 256, 5, None, None, 30.0, 30.0, None, None, None, None, 0, None),
+        "mri_siren_backward": (None, None, 8, 3, 256, 5, None, None, None, None, None, None, 0, None, 0,
+                               None),
+        "mri_siren_forward_loss": (None, None, 8, 8, 3, 256, 5, None, None, 30.0, 30.0, 1.0, None, None)
+                                  + (None,) * 7 + (0, None),
         "mri_sample_indices": (1, 0, 10, 5, 4, None, None),
         "mri_gather_batch": (None, 4, 3, None, None, None, None, None, None, None),
     }
@@ -95,6 +100,12 @@ def test_every_entry_point_rejects_null_buffers_before_touching_the_device(lib):
     assert h.mri_hashgrid_forward(desc, None, -1, None, None, 2, 2, 1, None) == -1
     assert "out of range" in h.mri_last_error().decode()
     assert h.mri_tiny_mlp_supported(32, 128, 1) == 1 and h.mri_tiny_mlp_supported(64, 128, 1) == 0
+    # SIREN workspaces: the forward one holds the split weights (6 H^2 bytes per hidden x hidden layer),
+    # the training one the slabs as well; unsupported shapes report -1
+    assert h.mri_siren_forward_workspace_bytes(256, 5) == 4 * 6 * 256 * 256
+    assert h.mri_siren_forward_workspace_bytes(64, 1) == 0
+    assert h.mri_siren_forward_workspace_bytes(96, 3) == -1
+    assert h.mri_siren_backward_workspace_bytes(1 << 12, 256, 5) > h.mri_siren_forward_workspace_bytes(256, 5)
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):
