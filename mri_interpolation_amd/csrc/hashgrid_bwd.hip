@@ -39,8 +39,11 @@ namespace {
 constexpr int kAccWords = 16384;  // 128 KiB of u64 accumulators per accumulate workgroup
 static_assert(kAccWords <= 65536, "record slots are stored in 16 bits");
 constexpr int kAccThreads = 1024;
-constexpr int kStageWords = 12288;  // 48 KiB LDS staging buffer of the scatter kernel (2 workgroups/CU)
-constexpr int kBinThreads = 512;
+#ifndef MRI_BIN_THREADS  // A/B builds (tools/build_variant.py): threads = coordinates of a scatter workgroup
+#define MRI_BIN_THREADS 512
+#endif
+constexpr int kBinThreads = MRI_BIN_THREADS;
+constexpr int kStageWords = 24 * kBinThreads;  // LDS staging buffer of the scatter kernel: 48 KiB, 2 workgroups/CU
 constexpr int kMaxParts = 256;        // slices per level handled by the binned path
 constexpr int kHeaderWords = 64;      // per-level max|g| bits
 constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
@@ -584,7 +587,7 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, Bin
   const int slots = kAccWords / F;
   plan.log2_slots = 31 - __builtin_clz((unsigned)slots);
   const int per_coord = (1 + F) << D;  // staging words per coordinate
-  plan.coords_per_block = std::min(512, kStageWords / per_coord / 64 * 64);
+  plan.coords_per_block = std::min(kBinThreads, kStageWords / per_coord / 64 * 64);
   const bool supported = D <= 4 && F <= 4 && plan.coords_per_block >= 64;
   const int target = options().bwd_blocks_per_level;
   for (int l = 0; l < g->n_levels; ++l) {

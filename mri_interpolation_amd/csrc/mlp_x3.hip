@@ -10,9 +10,10 @@
 // of 4, 96 KiB for W2's terms alone), so the roles of mlp_fused.hip are swapped:
 //
 //   * WEIGHTS LIVE IN REGISTERS.  The workgroup is 8 waves, wave w owns hidden units 16 w .. 16 w + 15
-//     in both hidden layers and holds, as ready-made MFMA operand fragments in their three terms,
-//     its rows of W1 and W2 (forward) and its columns of W2 (backward): 108 registers, loaded and
-//     split once per launch.  Its slices of dW2 (16 x 128) and dW1 (16 x 32) are MFMA accumulators
+//     in both hidden layers and holds, as ready-made MFMA operand fragments, the two larger terms
+//     of its rows of W2 (forward) and of its columns of W2 (backward): 64 registers, loaded and
+//     split once per launch.  W2's third term (one MFMA in six) and all of W1 are LDS images read
+//     row-wise and transposed.  Its slices of dW2 (16 x 128) and dW1 (16 x 32) are MFMA accumulators
 //     that live across all tiles.
 //   * ACTIVATIONS LIVE IN LDS as three-term bf16 images [32 rows][128 units] (x: [32][32]), written
 //     once by the wave that produced the units and read by all eight: row-wise (ds_read_b128) as
@@ -21,9 +22,10 @@
 //   * v_mfma_f32_16x16x32_bf16 with the weights in the A slot: the accumulator then holds, per lane,
 //     four CONSECUTIVE units of one row -- one packed 8-byte LDS store per term.
 //
-// A 32-row tile takes five workgroup barriers (x ready | h1 | h2 -> y | dz2 | dz1); two waves per
-// SIMD cover each other's LDS latencies, and VALU epilogues (bias, ReLU, the exact split: 5.5
-// instructions per element) of one wave run beside the other's MFMAs.
+// A 32-row tile takes four workgroup barriers (see the schedule in the kernel); two waves per SIMD
+// cover each other's LDS latencies, and VALU epilogues (bias, ReLU, the exact split: 5.5
+// instructions per element) of one wave run beside the other's MFMAs.  DESIGN.md 4.9 has the
+// measurements and what was tried.
 #include <algorithm>
 
 #include "bf16x3.h"
