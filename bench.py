@@ -32,6 +32,12 @@ MFMA_F32_PEAK_TF = 157.3  # exact-f32 matrix rate (no xf32 on gfx950)
 # ALGORITHMIC (f32) flops is the dense bf16 peak (16 x the f32 MFMA rate, MI355X_MICROARCH.md) / 6.
 MFMA_BF16_PEAK_TF = 16 * MFMA_F32_PEAK_TF
 MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6
+# what "dtype": "f32" means here, said in the line itself: every value is f32 and every result is within
+# f32 rounding of an f32 evaluation; the matrix products reach that on the bf16 pipe
+ARITHMETIC = ("f32 values and f32 accumulation everywhere; matrix products as six bf16 MFMAs per product on "
+              "operands split EXACTLY into three bf16 terms (per-product error below f32 rounding, measured "
+              "equal to v_mfma_f32_32x32x2_f32: DESIGN.md 4.9, tests/test_bf16x3_cpu.py); hash / gather / "
+              "scatter / Adam in plain f32 and 64-bit fixed point")
 
 
 def mfma_roof(step, achieved_tf):
@@ -226,7 +232,8 @@ def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
     result = {"metric": "coord-samples/sec (predict)", "value": value, "unit": "coord-samples/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": data_name,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC,
+              "data": data_name,
               "config": {"workload": f"{args.workload} predict: dense grid "
                                      f"{'x'.join(map(str, full.shape))}, {w['model']}, "
                                      f"batch {batch} coords per GPU and step",
@@ -408,6 +415,7 @@ def main():
         "metric": "coord-samples/sec (train)", "value": value, "unit": "coord-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "arithmetic": ARITHMETIC,
         "data": data_name,
         "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} "
                                f"{'sample volume' if w.get('sample_volume') else 'analytic phantom'}"
