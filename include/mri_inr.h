@@ -128,6 +128,21 @@ int mri_hashgrid_backward_levels(const mri_grid_desc* grid, const float* x, cons
                                  int64_t dout_feat_stride, float* d_table, int32_t method,
                                  uint32_t level_mask, void* workspace, int64_t workspace_bytes,
                                  void* stream);
+/* Table gradient AND the table's optimiser step in one pass (one rank, no gradient accumulation):
+ * embedding_dense_backward x L followed by torch.optim.Adam.step on the embedding weights (reference
+ * models.py:68-70 configure_optimizers, :61-66 training_step).  Where a gradient entry is complete
+ * the Adam update of mri_adam_step (same operations, same order: bit-identical results) is applied
+ * to table / exp_avg / exp_avg_sq in place; the gradient itself is never written (8 bytes of HBM
+ * traffic per table parameter and step less, and the optimiser launch shrinks to the decoder).
+ * `step` is the 1-based step number, `grad_scale` multiplies the gradient first.  method: 0 / 2
+ * (+ MRI_BWD_PREPARED); returns MRI_ERR_UNSUPPORTED if a level of the grid would take the atomic
+ * kernel (then call mri_hashgrid_backward + mri_adam_step). */
+int mri_hashgrid_backward_adam(const mri_grid_desc* grid, const float* x, const float* d_out,
+                               int64_t n, int64_t dout_level_stride, int64_t dout_row_stride,
+                               int64_t dout_feat_stride, float* table, float* exp_avg,
+                               float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                               int32_t step, float grad_scale, int32_t method, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 /* ---- fully connected layers (f32 MFMA) ------------------------------------------------
  * y = act(w0 * (x W^T + b))   with W (N, K) row-major as nn.Linear / SirenLayer store it.

@@ -13,6 +13,7 @@ ACT_IDENTITY, ACT_RELU, ACT_SINE, ACT_GELU = 0, 1, 2, 3
 DERIV_NONE, DERIV_MUL, DERIV_RELU_MASK = 0, 1, 2
 BWD_PREPARED = 16
 BWD_OVERWRITE = 32
+ERR_UNSUPPORTED = -2
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmri_inr.so")
 if os.environ.get("MRI_LIB"):  # tuning: an alternative build of the same sources (tools/)
@@ -47,6 +48,8 @@ SIGNATURES = {
     "mri_hashgrid_backward_levels": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32,
                                      C.c_uint32, _P, _I64, _P],
     "mri_hashgrid_backward_prepare": [C.POINTER(GridDesc), _P, _I64, _I32, _P, _I64, _P],
+    "mri_hashgrid_backward_adam": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _D, _D,
+                                   _D, _D, _I32, _F, _I32, _P, _I64, _P],
     "mri_linear_forward": [_P, _I64, _I64, _P, _P, _I64, _I32, _I32, _I32, _F, _P, _I64, _P,
                            _I64, _P],
     "mri_linear_backward_data": [_P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _I64, _I64,

@@ -30,6 +30,7 @@
 // Algorithmic traffic: records are 2 + 4 F bytes (16-bit slot within the slice + F values),
 // written once and read once.
 #include <algorithm>
+#include <cmath>
 
 #include "hashgrid_common.h"
 
@@ -323,6 +324,29 @@ __global__ __launch_bounds__(256) void bin_prefix_kernel(uint32_t* __restrict__ 
   if (threadIdx.x == 255) offsets[total_bins] = run;
 }
 
+// Adam fused into the last stage (one rank, no gradient accumulation): where a table gradient entry
+// is complete -- a slice's sole accumulate workgroup, or the finalize pass -- the update of
+// torch.optim.Adam (train_ops.hip: adam_kernel, the same operations in the same order) is applied to
+// the parameter and its two moments right there; the gradient never goes to HBM (8 bytes per table
+// parameter and step) and the optimiser launch shrinks to the decoder's parameters.
+struct AdamFuse {
+  float* p;  // the table itself (null: not fused, the gradient is written as before)
+  float* m;
+  float* v;
+  float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale;
+};
+
+__device__ __forceinline__ void adam_apply(const AdamFuse& a, uint64_t idx, float g) {
+  const float gr = g * a.grad_scale;
+  float m = a.m[idx], v = a.v[idx];
+  m = m + (gr - m) * a.one_minus_b1;
+  v = v * a.b2 + (a.one_minus_b2 * gr) * gr;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  a.m[idx] = m;
+  a.v[idx] = v;
+  a.p[idx] = a.p[idx] + (a.neg_step_size * m) / denom;
+}
+
 // ------------------------------------------------------------------------------ 5. accumulate
 template <int F>
 __device__ __forceinline__ void bin_accumulate_body(
@@ -330,7 +354,7 @@ __device__ __forceinline__ void bin_accumulate_body(
     int64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
     const uint16_t* __restrict__ rec_slot, const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
-    unsigned long long* __restrict__ partial, int overwrite) {
+    unsigned long long* __restrict__ partial, int overwrite, const AdamFuse& ad) {
   int e = 0;
   while (e + 1 < plan.n_entries && b >= plan.acc_start[e + 1]) ++e;
   const int level = plan.level_of[e];
@@ -344,7 +368,10 @@ __device__ __forceinline__ void bin_accumulate_body(
   const uint32_t per = ((r_cnt + splits - 1) / splits + 3u) & ~3u;
   const uint32_t k_lo = min(r_cnt, (uint32_t)split * per), k_hi = min(r_cnt, k_lo + per);
   if (k_lo >= k_hi) {  // nothing routed here (uniform for the workgroup)
-    if (overwrite && plan.ws_offset[e] < 0) {
+    if (ad.p && plan.ws_offset[e] < 0) {  // zero gradient: the moments still decay, the parameter still moves
+      const uint64_t first = (tab.offset[level] + base) * F;
+      for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) adam_apply(ad, first + s, 0.0f);
+    } else if (overwrite && plan.ws_offset[e] < 0) {
       float* __restrict__ dst = d_table + (tab.offset[level] + base) * F;
       for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) dst[s] = 0.0f;
     }
@@ -352,6 +379,23 @@ __device__ __forceinline__ void bin_accumulate_body(
   }
 
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
+  // fused Adam: this slice's parameters and moments are fetched NOW, before the record phase (read at
+  // the end they would add their full HBM latency to every workgroup: 0.21 -> 0.28 ms measured)
+  constexpr int kPre = kAccWords / kAccThreads;
+  const bool fuse_here = ad.p != nullptr && plan.ws_offset[e] < 0;
+  const uint64_t first_word = (tab.offset[level] + base) * F;
+  float pre_p[kPre], pre_m[kPre], pre_v[kPre];
+  if (fuse_here) {
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const uint32_t s = threadIdx.x + j * kAccThreads;
+      if (s < count * F) {
+        pre_p[j] = ad.p[first_word + s];
+        pre_m[j] = __builtin_nontemporal_load(ad.m + first_word + s);
+        pre_v[j] = __builtin_nontemporal_load(ad.v + first_word + s);
+      }
+    }
+  }
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
@@ -410,7 +454,21 @@ __device__ __forceinline__ void bin_accumulate_body(
   if (ws_off < 0) {  // sole owner of the slice: convert once, add to the f32 gradient
     const double inv_scale = __builtin_ldexp(1.0, -ex);
     float* __restrict__ dst = d_table + (tab.offset[level] + base) * F;
-    if (overwrite) {
+    if (fuse_here) {
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const uint32_t s = threadIdx.x + j * kAccThreads;
+        if (s < count * F) {
+          const float gr = (float)((double)(long long)acc[s] * inv_scale) * ad.grad_scale;
+          const float m = pre_m[j] + (gr - pre_m[j]) * ad.one_minus_b1;
+          const float v = pre_v[j] * ad.b2 + (ad.one_minus_b2 * gr) * gr;
+          const float denom = sqrtf(v) / ad.bc2_sqrt + ad.eps;
+          __builtin_nontemporal_store(m, ad.m + first_word + s);
+          __builtin_nontemporal_store(v, ad.v + first_word + s);
+          ad.p[first_word + s] = pre_p[j] + (ad.neg_step_size * m) / denom;
+        }
+      }
+    } else if (overwrite) {
       for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
         dst[s] = (float)((double)(long long)acc[s] * inv_scale);
     } else {
@@ -432,10 +490,10 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
     const float* __restrict__ rec_val, int64_t records,
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
-    unsigned long long* __restrict__ partial, int overwrite) {
+    unsigned long long* __restrict__ partial, int overwrite, const AdamFuse ad) {
   __shared__ unsigned long long acc[kAccWords];
   bin_accumulate_body<F>(acc, blockIdx.x, tab, plan, n, offsets, counts, rec_slot, rec_val,
-                         records, max_bits, d_table, partial, overwrite);
+                         records, max_bits, d_table, partial, overwrite, ad);
 }
 
 // ------------------------------------------------------------------------- coarse levels
@@ -538,14 +596,15 @@ __global__ __launch_bounds__(kAccThreads) void dense_and_accumulate_kernel(
     int64_t sr, int64_t sf, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
     const float* __restrict__ rec_val, int64_t records, const uint32_t* __restrict__ max_bits,
-    float* __restrict__ d_table, unsigned long long* __restrict__ partial, int overwrite) {
+    float* __restrict__ d_table, unsigned long long* __restrict__ partial, int overwrite,
+    const AdamFuse ad) {
   __shared__ unsigned long long acc[kAccWords];
   const int b = blockIdx.x;
   if (b < dense_blocks)
     dense_level_body<D, F>(acc, b, tab, dense, x, d_out, n, sl, sr, sf, max_bits, partial);
   else
     bin_accumulate_body<F>(acc, b - dense_blocks, tab, plan, n, offsets, counts, rec_slot,
-                           rec_val, records, max_bits, d_table, partial, overwrite);
+                           rec_val, records, max_bits, d_table, partial, overwrite, ad);
 }
 
 // ------------------------------------------------------------------------------ 6. finalize
@@ -554,7 +613,7 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, c
                                                            float* __restrict__ d_table,
                                                            const uint32_t* __restrict__ max_bits,
                                                            const unsigned long long* __restrict__ partial,
-                                                           int overwrite) {
+                                                           int overwrite, const AdamFuse ad) {
   const int e = blockIdx.y;
   if (plan.ws_offset[e] < 0) return;
   const int level = plan.level_of[e];
@@ -565,7 +624,9 @@ __global__ __launch_bounds__(256) void bin_finalize_kernel(const LevelTab tab, c
   for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < words;
        s += (uint64_t)gridDim.x * 256) {
     const long long v = (long long)src[s];
-    if (overwrite)
+    if (ad.p)
+      adam_apply(ad, tab.offset[level] * F + s, (float)((double)v * inv_scale));
+    else if (overwrite)
       dst[s] = (float)((double)v * inv_scale);
     else if (v)
       dst[s] += (float)((double)v * inv_scale);
@@ -712,7 +773,7 @@ struct BinnedLaunch {
   static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense_all,
                  const Workspace& w, int n_levels, uint32_t level_mask, int phase, int overwrite,
                  const float* x, const float* d_out, int64_t n, int64_t sl, int64_t sr,
-                 int64_t sf, float* d_table, hipStream_t st) {
+                 int64_t sf, float* d_table, const AdamFuse& ad, hipStream_t st) {
     // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
     // forward pass); 2: the rest, after a phase-1 call on the same workspace
     if constexpr (D <= 4 && F <= 4) {
@@ -754,7 +815,7 @@ struct BinnedLaunch {
       auto finalize = [&]() {
         if (fin.n_entries > 0)
           hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, fin.n_entries), dim3(256), 0, st, tab,
-                             fin, F, n, d_table, w.max_bits, w.partial, overwrite);
+                             fin, F, n, d_table, w.max_bits, w.partial, overwrite, ad);
       };
       if (plan.n_entries == 0) {
         finalize();
@@ -789,12 +850,12 @@ struct BinnedLaunch {
                            dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
                            tab, dense, dense_blocks, sel, x, d_out, n, sl, sr, sf, w.offsets,
                            w.counts, w.rec_slot, w.rec_val, w.records, w.max_bits, d_table,
-                           w.partial, overwrite);
+                           w.partial, overwrite, ad);
       else
         hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
                            dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts,
                            w.rec_slot, w.rec_val, w.records, w.max_bits, d_table, w.partial,
-                           overwrite);
+                           overwrite, ad);
       finalize();
       return check_launch("hashgrid backward (binned)");
     } else {
@@ -823,19 +884,24 @@ namespace {
 int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
                   int64_t sl, int64_t sr, int64_t sf, float* d_table, int32_t method, int phase,
                   int overwrite, uint32_t level_mask, void* workspace,
-                  int64_t workspace_bytes_given, void* stream) {
+                  int64_t workspace_bytes_given, void* stream, const AdamFuse* fuse = nullptr) {
   if (int rc = validate(grid)) return rc;
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
   if (n == 0) return MRI_OK;
-  MRI_REQUIRE(x && (phase == 1 || (d_out && d_table)), "NULL device pointer");
+  MRI_REQUIRE(x && (phase == 1 || (d_out && (d_table || fuse))), "NULL device pointer");
   const int F = grid->n_features;
+  const AdamFuse ad = fuse ? *fuse : AdamFuse{};
   BinPlan plan, dense;
   uint32_t atomic_mask;
   int64_t ws_words, records;
   int acc_blocks, dense_blocks;
-  if (make_plan(grid, n, method, plan, dense, dense_blocks, atomic_mask, ws_words, records,
-                acc_blocks)) {
+  const bool planned = make_plan(grid, n, method, plan, dense, dense_blocks, atomic_mask, ws_words,
+                                 records, acc_blocks);
+  if (fuse && (!planned || atomic_mask != 0))
+    return fail(MRI_ERR_UNSUPPORTED, "fused Adam needs every level on the binned path "
+                                     "(a level of this grid takes the atomic kernel)");
+  if (planned) {
     MRI_REQUIRE(records < (1ll << 32), "too many gradient records (%lld)", (long long)records);
     const int64_t need = workspace_bytes(plan, n, ws_words, records, F);
     MRI_REQUIRE(workspace != nullptr && workspace_bytes_given >= need,
@@ -848,7 +914,7 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
     const LevelTab tab = make_tab(grid);
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, w, grid->n_levels,
                                     level_mask, phase, overwrite, x, d_out, n, sl, sr, sf,
-                                    d_table, (hipStream_t)stream);
+                                    d_table, ad, (hipStream_t)stream);
     if (rc) return rc;
   }
   atomic_mask &= level_mask;
@@ -893,4 +959,26 @@ extern "C" int mri_hashgrid_backward_levels(const mri_grid_desc* grid, const flo
   return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
                        d_table, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, overwrite,
                        level_mask, workspace, workspace_bytes_given, stream);
+}
+
+extern "C" int mri_hashgrid_backward_adam(const mri_grid_desc* grid, const float* x,
+                                          const float* d_out, int64_t n,
+                                          int64_t dout_level_stride, int64_t dout_row_stride,
+                                          int64_t dout_feat_stride, float* table, float* exp_avg,
+                                          float* exp_avg_sq, double lr, double beta1, double beta2,
+                                          double eps, int32_t step, float grad_scale, int32_t method,
+                                          void* workspace, int64_t workspace_bytes_given,
+                                          void* stream) {
+  MRI_REQUIRE(table && exp_avg && exp_avg_sq && step >= 1, "NULL parameter / moment pointer or step < 1");
+  AdamFuse ad{};
+  ad.p = table, ad.m = exp_avg, ad.v = exp_avg_sq;
+  // scalar prefactors in double, as torch computes them on the host (mri_adam_step)
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  ad.one_minus_b1 = (float)(1.0 - beta1), ad.b2 = (float)beta2, ad.one_minus_b2 = (float)(1.0 - beta2);
+  ad.neg_step_size = (float)(-(lr / bc1)), ad.bc2_sqrt = (float)sqrt(bc2), ad.eps = (float)eps;
+  ad.grad_scale = grad_scale;
+  const int phase = (method & MRI_BWD_PREPARED) ? 2 : 0;
+  return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
+                       nullptr, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, 1, 0xffffffffu,
+                       workspace, workspace_bytes_given, stream, &ad);
 }

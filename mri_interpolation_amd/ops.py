@@ -166,6 +166,37 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
     return d_table
 
 
+def hashgrid_backward_adam(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor, table: torch.Tensor,
+                           exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float, beta1: float,
+                           beta2: float, eps: float, step: int, grad_scale: float = 1.0,
+                           feature_major: bool = False, method: int = 0, prepared: bool = False,
+                           ws: Optional[torch.Tensor] = None) -> bool:
+    """Table gradient and the table's Adam step in one pass (mri_hashgrid_backward_adam): `table`,
+    `exp_avg`, `exp_avg_sq` are updated in place, no gradient tensor is produced.  Returns False
+    (nothing done) when a level of the grid is not served by the binned kernels."""
+    _gpu(x, d_out, table, exp_avg, exp_avg_sq)
+    x = _rowmajor(x).contiguous()
+    n = x.shape[0]
+    if not d_out.is_contiguous():
+        d_out = d_out.contiguous()
+    if not (table.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()):
+        raise ValueError("hashgrid_backward_adam needs contiguous table / moment buffers")
+    sl, sr, sf = _enc_strides(desc, n, feature_major)
+    if method == 1:
+        return False
+    if ws is None:
+        ws = backward_workspace(desc, n, x.device)
+    flags = method | (_lib.BWD_PREPARED if prepared else 0)
+    rc = _lib.load().mri_hashgrid_backward_adam(
+        C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf, _ptr(table), _ptr(exp_avg), _ptr(exp_avg_sq),
+        float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale), flags, _ptr(ws),
+        ws.numel() * 8, _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    _lib.check(rc, "mri_hashgrid_backward_adam")
+    return True
+
+
 def hashgrid_backward_input(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                             table: torch.Tensor, feature_major: bool = False) -> torch.Tensor:
     """d loss / d x (n, D): the reference keeps x -> x*res - trunc(x*res) differentiable

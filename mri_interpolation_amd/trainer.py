@@ -90,6 +90,12 @@ class FusedStep:
         # train_step folds the loss and the head's backward into the forward kernel (needs a
         # sine layer below the last one); forward() + backward() keep the separate kernels
         self.chain_loss = self.use_chain and len(self.layers) >= 3
+        # one rank, no accumulation: the table's Adam update runs where its gradient is complete
+        # (mri_hashgrid_backward_adam); the table part of flat.grad is then NOT produced.  Bit-identical
+        # to the two launches; measured 0.574 -> 0.562 ms on config 4 but 0.451 -> 0.460 on config 2
+        # and 0.869 -> 0.885 on config 5: off by default
+        self.fuse_table_adam = False
+        self._table_stepped = False
         # Data parallel: the table gradient is produced level by level, so its reduction is cut
         # into `grad_buckets` level groups; group g's all-reduce (RCCL, its own stream) runs
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
@@ -338,6 +344,36 @@ class FusedStep:
             pending.append(self._reduce_async(grad_slice))
         return pending
 
+    def _table_range(self):
+        f = self.encoder.n_features_per_level
+        t0 = self.flat.offsets[next(k for k, q in enumerate(self.flat.params)
+                                    if q is self.encoder.table)]
+        return t0, t0 + self.encoder.table.shape[0] * f
+
+    def _hash_backward_adam(self, coords, d_enc) -> bool:
+        """Table gradient + the table's Adam step in one pass; False if this grid / configuration
+        cannot take it (the caller then runs the two-launch form)."""
+        if not (self.fuse_table_adam and self.world == 1 and self.bwd_method != 1):
+            return False
+        enc = self.encoder
+        if self._counted:
+            torch.cuda.current_stream().wait_stream(self._side)
+        counted = self._counted
+        t0, t1 = self._table_range()
+        o = self.opt
+        o.begin_step()
+        ok = ops.hashgrid_backward_adam(
+            enc.desc, coords, d_enc, self.flat.param[t0:t1], self.flat.exp_avg[t0:t1],
+            self.flat.exp_avg_sq[t0:t1], o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.eps,
+            o.step_count, o.grad_scale, feature_major=True, method=self.bwd_method, prepared=counted,
+            ws=self._hash_workspace(coords.shape[0]))
+        if not ok:
+            o.step_count -= 1  # nothing was done: the ordinary path opens the step itself
+            return False
+        self._counted = False
+        self._table_stepped = True
+        return True
+
     def _reduce_async(self, grad_slice):
         """(handle, lo, hi): a started reduction of flat.grad[lo:hi]."""
         lo = grad_slice.storage_offset() - self.flat.grad.storage_offset()
@@ -408,8 +444,11 @@ class FusedStep:
                                        grad_divisor=div, overwrite=first)
             started = self._reduce_decoder_grads() if step else []
             with self._phase("hashgrid_bwd"):
-                self._pending = started + self._hash_backward(coords, ws["d_enc"],
-                                                              overwrite=first, reduce=step)
+                if first and step and self._hash_backward_adam(coords, ws["d_enc"]):
+                    self._pending = []
+                else:
+                    self._pending = started + self._hash_backward(coords, ws["d_enc"],
+                                                                  overwrite=first, reduce=step)
             return
         with self._phase("zero_grad"):
             if first:
@@ -519,6 +558,14 @@ class FusedStep:
                 for handle, lo, hi in self._pending:
                     parallel.wait_all([handle])
                     self.opt.step_range(lo, hi)
+        elif self._table_stepped:  # the table was stepped with its gradient: the rest of the buffer
+            self._table_stepped = False
+            t0, t1 = self._table_range()
+            with self._phase("adam"):
+                if t0 > 0:
+                    self.opt.step_range(0, t0)
+                if t1 < self.flat.numel:
+                    self.opt.step_range(t1, self.flat.numel)
         else:
             if self.world > 1:
                 with self._phase("all_reduce"):

@@ -750,3 +750,53 @@ def test_data_parallel_step_through_one_rank_rccl(amd):
     finally:
         parallel.all_reduce_async, parallel.reduce_scatter_sum, parallel.all_gather_shards = real
         dist.destroy_process_group()
+
+
+# ------------------------------------------------- the table's Adam step fused into its gradient
+@pytest.mark.parametrize("dim,hidden,n,log2t", [(3, 128, 1 << 18, 19), (3, 64, 70001, 15), (4, 128, 5000, 14),
+                                               (2, 64, 33, 12)])
+def test_fused_table_adam_equals_the_two_launch_step(amd, dim, hidden, n, log2t):
+    """FusedStep.fuse_table_adam (mri_hashgrid_backward_adam: the Adam update applied where a table
+    gradient entry is complete, no gradient tensor) against table gradient + mri_adam_step: the same
+    operations in the same order, so parameters AND both moments stay bit-identical over several
+    steps, for dense, single-bin and split-bin levels; the decoder's gradients are untouched."""
+    torch.manual_seed(dim * 100 + hidden)
+    net = amd.models.HashMLP(dim, 16, 2, log2t, 16, 512, dim_hidden=hidden, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False, lr=5e-3)
+    with torch.no_grad():
+        net.encoder.table.uniform_(-0.5, 0.5)
+    nets = [net.cuda(), copy.deepcopy(net).cuda()]
+    steps = [amd.trainer.FusedStep(q, q.configure_optimizers()) for q in nets]
+    steps[0].fuse_table_adam = True
+    g = torch.Generator().manual_seed(n)
+    for k in range(4):
+        x, y = torch.rand(n, dim, generator=g).cuda(), torch.rand(n, 1, generator=g).cuda()
+        la, lb = steps[0].train_step(x, y), steps[1].train_step(x, y)
+        assert float(la) == float(lb)
+        assert torch.equal(steps[0].flat.param, steps[1].flat.param), k
+        assert torch.equal(steps[0].flat.exp_avg, steps[1].flat.exp_avg), k
+        assert torch.equal(steps[0].flat.exp_avg_sq, steps[1].flat.exp_avg_sq), k
+        assert steps[0].opt.step_count == steps[1].opt.step_count == k + 1
+    t0, t1 = steps[0]._table_range()
+    assert torch.equal(steps[0].flat.grad[t1:], steps[1].flat.grad[t1:])  # decoder gradients as ever
+    # gradient accumulation keeps the two-launch form (the gradient of a group is not complete in one pass)
+    la = steps[0].train_step(x, y, first=True, step=False, divisor=2)
+    lb = steps[1].train_step(x, y, first=True, step=False, divisor=2)
+    la = steps[0].train_step(x, y, first=False, step=True, divisor=2)
+    lb = steps[1].train_step(x, y, first=False, step=True, divisor=2)
+    assert torch.equal(steps[0].flat.param, steps[1].flat.param)
+
+
+def test_fused_table_adam_declines_what_it_cannot_serve(amd):
+    """A grid with a level on the atomic kernel (more than 256 slices), or method 1: the fused entry
+    reports 'unsupported' and the step falls back to the two launches."""
+    net = amd.models.HashMLP(3, 2, 2, 22, 16, 2048, dim_hidden=64, n_layers=3, activation=torch.nn.ReLU,
+                             batch_norm=False, final_activation=False, lr=5e-3).cuda()
+    ref = copy.deepcopy(net)
+    a = amd.trainer.FusedStep(net, net.configure_optimizers())
+    b = amd.trainer.FusedStep(ref, ref.configure_optimizers())
+    a.fuse_table_adam = True
+    x, y = torch.rand(4096, 3, device="cuda"), torch.rand(4096, 1, device="cuda")
+    for _ in range(2):
+        a.train_step(x, y), b.train_step(x, y)
+    assert a.opt.step_count == 2 and torch.equal(a.flat.param, b.flat.param)
