@@ -672,6 +672,163 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   X3P_END
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Inference form for H = 128 (dense-grid predict / interpolate passes, launcher.py:150-185): the same
+// arithmetic per row as the training kernel's forward half (bit-identical predictions), on 64-row
+// tiles with two barriers per tile -- no gradient images, so the h1 image can be twice as tall, and
+// all three terms of the wave's W2 rows fit in registers.
+struct __attribute__((aligned(16))) X3InferSmem {
+  char x[2][3][64 * 64];     // input tile [64 rows][32 features], three terms, double-buffered
+  char h1[3][64 * 256];
+  char w1[3][4 * kImg32Bytes];
+  float ypart[8][64];
+  float b1[kX3H], b2[kX3H], w3[kX3H];
+};
+
+__global__ __launch_bounds__(kX3Threads) void tiny_mlp_x3_infer_kernel(const FusedArgs a) {
+  constexpr int H = kX3H, ROWS = 64, NSUB = 4, XT = 64 * 64, HT = 64 * 256;
+  __shared__ X3InferSmem sm;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Frag w2f[4];
+  {
+    const int n = 16 * w + li;
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = a.w2[n * H + 32 * s + 8 * g + j];
+      w2f[s] = split8(v);
+    }
+  }
+  for (int e = tid; e < H * 16; e += kX3Threads) {
+    const int n = e >> 4, kp = e & 15;
+    const float v0 = 2 * kp < a.k_in ? a.w1[n * a.k_in + 2 * kp] : 0.f;
+    const float v1 = 2 * kp + 1 < a.k_in ? a.w1[n * a.k_in + 2 * kp + 1] : 0.f;
+    uint32_t h, m, l;
+    split2(v0, v1, h, m, l);
+    const int off = img32_off(n, kp >> 2) + 4 * (kp & 3);
+    *reinterpret_cast<uint32_t*>(sm.w1[0] + off) = h;
+    *reinterpret_cast<uint32_t*>(sm.w1[1] + off) = m;
+    *reinterpret_cast<uint32_t*>(sm.w1[2] + off) = l;
+  }
+  if (tid < H) sm.b1[tid] = a.b1[tid], sm.b2[tid] = a.b2[tid], sm.w3[tid] = a.w3[tid];
+  const float b3 = a.b3[0];
+
+  const int swl = sw(li), q4 = li >> 2;
+  int a_row = 256 * li + 16 * (g ^ (swl & 3)) + 64 * (swl >> 2);  // (a_row ^ 64 s) + 4096 t, see the training kernel
+  int a_row32 = 64 * li + 16 * (g ^ ((4 - q4) & 3));               // + 1024 t
+  const int a_out = 256 * li + 8 * (g & 1) + 16 * ((g >> 1) ^ (swl & 1)) + ((32 * w) ^ (16 * (swl & 14)));
+  char* const smb = reinterpret_cast<char*>(&sm);
+  char* const i_h1 = smb + offsetof(X3InferSmem, h1);
+  const char* const i_w1 = smb + offsetof(X3InferSmem, w1);
+  const uint32_t ld32 = (uint32_t)a.ld;
+  float xv[2][2];
+  auto load_x = [&](int64_t m0) {  // thread = (row sb of 64, feature pairs skp and skp + 8)
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    const int sb = t_op & 63, skp = t_op >> 6;
+    const float* __restrict__ xs = a.x + m0;
+    const bool live = sb < a.n - m0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = 2 * (skp + 8 * q);
+      xv[q][0] = (live && k < a.k_in) ? xs[(uint32_t)k * ld32 + sb] : 0.f;
+      xv[q][1] = (live && k + 1 < a.k_in) ? xs[(uint32_t)(k + 1) * ld32 + sb] : 0.f;
+    }
+  };
+  auto store_x = [&](int buf) {
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    const int sb = t_op & 63, skp = t_op >> 6;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      uint32_t h, m, l;
+      split2(xv[q][0], xv[q][1], h, m, l);
+      const int kp = skp + 8 * q;
+      const int off = img32_off(sb, kp >> 2) + 4 * (kp & 3);
+      *reinterpret_cast<uint32_t*>(sm.x[buf][0] + off) = h;
+      *reinterpret_cast<uint32_t*>(sm.x[buf][1] + off) = m;
+      *reinterpret_cast<uint32_t*>(sm.x[buf][2] + off) = l;
+    }
+  };
+  auto layer1 = [&](int xbuf) {
+    const char* const i_x = smb + offsetof(X3InferSmem, x) + xbuf * (3 * XT);
+    const Frag w1f = ld_row<4 * kImg32Bytes>(i_w1, a_row32 + 1024 * w);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.b1[16 * w + 4 * g]);
+    Frag xb[2];
+    xb[0] = ld_row<XT>(i_x, a_row32);
+#pragma unroll
+    for (int t = 0; t < NSUB; ++t) {
+      if (t + 1 < NSUB) xb[(t + 1) & 1] = ld_row<XT>(i_x, a_row32 + 1024 * (t + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x4 c = mma6(w1f, xb[t & 1], zero4);
+      __builtin_amdgcn_sched_barrier(0);
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = fmaxf(c[r] + bias[r], 0.f);
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split2(h[0], h[1], h0, m0, l0);
+      split2(h[2], h[3], h1, m1, l1);
+      const int off = a_out + 4096 * t;
+      *reinterpret_cast<u32x2*>(i_h1 + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(i_h1 + HT + off) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(i_h1 + 2 * HT + off) = u32x2{l0, l1};
+    }
+  };
+
+  const int64_t tiles = (a.n + ROWS - 1) / ROWS, stride = gridDim.x;
+  int buf = 0;
+  load_x((int64_t)blockIdx.x * ROWS);
+  store_x(0);
+  if (blockIdx.x + stride < tiles) load_x((blockIdx.x + stride) * ROWS);
+  __syncthreads();
+  layer1(0);
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += stride, buf ^= 1) {
+    asm volatile("" : "+v"(a_row), "+v"(a_row32));
+    const int64_t m0 = tile * ROWS;
+    const bool has_next = tile + stride < tiles, has_next2 = tile + 2 * stride < tiles;
+    __syncthreads();  // h1 of this tile complete
+    // ---- layer 2 and this strip's share of y; the next tile's input goes to LDS meanwhile ---------
+    {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(&sm.b2[16 * w + 4 * g]);
+      const f32x4 w3v = *reinterpret_cast<const f32x4*>(&sm.w3[16 * w + 4 * g]);
+      Frag hb[2];
+      hb[0] = ld_row<HT>(i_h1, a_row);
+#pragma unroll
+      for (int t = 0; t < NSUB; ++t) {
+        f32x4 c = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int i = 4 * t + s;
+          if (i + 1 < 4 * NSUB)
+            hb[(i + 1) & 1] = ld_row<HT>(i_h1, (a_row ^ (64 * ((s + 1) & 3))) + 4096 * ((i + 1) >> 2));
+          __builtin_amdgcn_sched_barrier(0);
+          c = mma6(w2f[s], hb[i & 1], c);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        float yp = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yp += w3v[r] * fmaxf(c[r] + bias[r], 0.f);
+        yp = sum_groups(yp);
+        if (g == 0) sm.ypart[w][16 * t + li] = yp;
+      }
+    }
+    if (has_next) store_x(buf ^ 1);
+    if (has_next2) load_x((tile + 2 * stride) * ROWS);
+    __syncthreads();  // y shares complete, x of the next tile staged, every wave done with h1
+    if (w == 0) {
+      float y = b3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y += sm.ypart[q][lane];
+      if (lane < a.n - m0) (a.y + m0)[lane] = y;
+    }
+    if (has_next) layer1(buf ^ 1);
+  }
+}
+
 }  // namespace
 
 bool x3_supported(int k_in, int hidden) { return (hidden == 128 || hidden == 64) && k_in >= 1 && k_in <= 32; }
@@ -680,8 +837,15 @@ bool x3_addressable(const FusedArgs& a) { return (int64_t)a.k_in * a.ld < (1ll <
 
 int x3_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, kX3Rows), 256); }
 
+bool x3_infer_wide(int hidden) { return hidden == 128 && options().mlp_x3 == 1; }
+
 int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st) {
   const bool wide = options().mlp_x3 == 2 && hidden == 128;  // 4 waves of two strips (tools: A/B against 8 x 1)
+  if (!train && x3_infer_wide(hidden)) {
+    const int ib = (int)std::min<int64_t>(ceil_div(a.n, 64), 256);
+    hipLaunchKernelGGL(tiny_mlp_x3_infer_kernel, dim3(ib), dim3(kX3Threads), 0, st, a);
+    return check_launch("tiny_mlp_x3_infer_kernel");
+  }
   if (hidden == 64 && train)
     hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a);
   else if (hidden == 64)
