@@ -122,6 +122,18 @@ __device__ __forceinline__ void wave_exclusive_scan(const uint32_t* in, uint32_t
   if (lane == 63) out[count] = incl;
 }
 
+// coordinates of a count / scatter workgroup, and threads per coordinate: the staging buffer holds
+// 2^D (1 + F) words per coordinate, so 4-D grids take 256 (128 with F = 4) coordinates per workgroup --
+// their 16 corners are then split over 2 (4) threads instead of leaving half the workgroup idle
+template <int D, int F>
+struct BinGeometry {
+  static constexpr int per_coord = (1 << D) * (1 + F);
+  static constexpr int coords = kStageWords / per_coord / 64 * 64 < kBinThreads
+                                    ? kStageWords / per_coord / 64 * 64 : kBinThreads;
+  static constexpr int tpc = coords >= 64 ? kBinThreads / coords : 1;  // threads per coordinate
+  static constexpr int corners = (1 << D) / tpc;                        // corners per thread
+};
+
 // ------------------------------------------------------------------------ 2. count / 4. scatter
 // One workgroup = (chunk of coords_per_block coordinates, level).  Both kernels walk the same
 // corners in the same way; `SCATTER` selects what is done with them.
@@ -186,12 +198,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     // count: how many corners of this chunk fall into each slice of the level
     for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;
     __syncthreads();
-    for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
+    using G = BinGeometry<D, F>;
+    const int sub = threadIdx.x % G::tpc;  // this thread's share of the corners
+    for (int64_t i = i_begin + threadIdx.x / G::tpc; i < i_end; i += kBinThreads / G::tpc) {
       uint32_t h0[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) h0[d] = cell_low32(x[i * D + d] * res[d]) * kPrimes[d];
 #pragma unroll
-      for (int nb = 0; nb < (1 << D); ++nb) {
+      for (int q = 0; q < G::corners; ++q) {
+        const int nb = sub * G::corners + q;
         uint32_t h = 0;
 #pragma unroll
         for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
@@ -221,7 +236,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   const uint32_t total = local_off[parts];
   const float* __restrict__ gl = d_out + (int64_t)level * sl;
   float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
-  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kBinThreads) {
+  using G = BinGeometry<D, F>;
+  const int sub = threadIdx.x % G::tpc;
+  for (int64_t i = i_begin + threadIdx.x / G::tpc; i < i_end; i += kBinThreads / G::tpc) {
     const Cell<D> c = locate<D>(x, i, res);
     float g[F];
 #pragma unroll
@@ -230,7 +247,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       gmax = fmaxf(gmax, fabsf(g[f]));
     }
 #pragma unroll
-    for (int nb = 0; nb < (1 << D); ++nb) {
+    for (int q = 0; q < G::corners; ++q) {
+      const int nb = sub * G::corners + q;
       uint32_t h;
       float w;
       corner<D>(c, nb, h, w);
