@@ -37,9 +37,15 @@
 namespace mri {
 namespace {
 
-constexpr int kAccWords = 16384;  // 128 KiB of u64 accumulators per accumulate workgroup
+#ifndef MRI_ACC_WORDS  // A/B builds: accumulators (and threads) of an accumulate workgroup
+#define MRI_ACC_WORDS 16384
+#endif
+#ifndef MRI_ACC_THREADS
+#define MRI_ACC_THREADS 1024
+#endif
+constexpr int kAccWords = MRI_ACC_WORDS;  // 128 KiB of u64 accumulators per accumulate workgroup
 static_assert(kAccWords <= 65536, "record slots are stored in 16 bits");
-constexpr int kAccThreads = 1024;
+constexpr int kAccThreads = MRI_ACC_THREADS;
 #ifndef MRI_BIN_THREADS  // A/B builds (tools/build_variant.py): threads = coordinates of a scatter workgroup
 #define MRI_BIN_THREADS 512
 #endif
