@@ -100,8 +100,6 @@ __device__ __forceinline__ int img32_off(int row, int ch) {
 }
 constexpr int kImg32Bytes = 32 * 64;
 
-typedef __attribute__((address_space(3))) char* lds_ptr;
-
 __device__ __forceinline__ u32x4 lds_read_b128(const char* p) {
   return *reinterpret_cast<const u32x4*>(p);
 }

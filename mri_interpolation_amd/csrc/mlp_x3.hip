@@ -74,39 +74,6 @@ struct __attribute__((aligned(16))) X3Smem {
   float b1[kX3H], b2[kX3H], w3[kX3H];  // read per tile (registers are the scarce resource here)
 };
 
-__device__ __forceinline__ Frag row_frag(const char (*img)[kImgBytes], int off) {
-  Frag f;
-  f.h = lds_read_b128(img[0] + off), f.m = lds_read_b128(img[1] + off), f.l = lds_read_b128(img[2] + off);
-  return f;
-}
-template <int BYTES>
-__device__ __forceinline__ Frag row_frag32(const char (*img)[BYTES], int off) {
-  Frag f;
-  f.h = lds_read_b128(img[0] + off), f.m = lds_read_b128(img[1] + off), f.l = lds_read_b128(img[2] + off);
-  return f;
-}
-__device__ __forceinline__ Frag tr_frag3(const char (*img)[kImgBytes], int c0, int lane) {
-  auto off = [](int row, int ch) { return img_off(row, ch); };
-  Frag f;
-  f.h = tr_frag(img[0], c0, lane, off), f.m = tr_frag(img[1], c0, lane, off), f.l = tr_frag(img[2], c0, lane, off);
-  return f;
-}
-__device__ __forceinline__ Frag tr_frag3_32(const char (*img)[kImg32Bytes], int c0, int lane) {
-  auto off = [](int row, int ch) { return img32_off(row, ch); };
-  Frag f;
-  f.h = tr_frag(img[0], c0, lane, off), f.m = tr_frag(img[1], c0, lane, off), f.l = tr_frag(img[2], c0, lane, off);
-  return f;
-}
-// four consecutive columns of one row, in the three terms
-__device__ __forceinline__ void store4(char (*img)[kImgBytes], int off, const float (&v)[4]) {
-  uint32_t h0, m0, l0, h1, m1, l1;
-  split2(v[0], v[1], h0, m0, l0);
-  split2(v[2], v[3], h1, m1, l1);
-  *reinterpret_cast<u32x2*>(img[0] + off) = u32x2{h0, h1};
-  *reinterpret_cast<u32x2*>(img[1] + off) = u32x2{m0, m1};
-  *reinterpret_cast<u32x2*>(img[2] + off) = u32x2{l0, l1};
-}
-
 // Three-term fragments at byte offset `off` of an image whose terms are TERM bytes apart.
 template <int TERM>
 __device__ __forceinline__ Frag ld_row(const char* img, int off) {
