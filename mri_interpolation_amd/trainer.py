@@ -361,15 +361,14 @@ class FusedStep:
         counted = self._counted
         t0, t1 = self._table_range()
         o = self.opt
-        o.begin_step()
         ok = ops.hashgrid_backward_adam(
             enc.desc, coords, d_enc, self.flat.param[t0:t1], self.flat.exp_avg[t0:t1],
             self.flat.exp_avg_sq[t0:t1], o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.eps,
-            o.step_count, o.grad_scale, feature_major=True, method=self.bwd_method, prepared=counted,
-            ws=self._hash_workspace(coords.shape[0]))
-        if not ok:
-            o.step_count -= 1  # nothing was done: the ordinary path opens the step itself
+            o.step_count + 1, o.grad_scale, feature_major=True, method=self.bwd_method,
+            prepared=counted, ws=self._hash_workspace(coords.shape[0]))
+        if not ok:  # nothing was done: the ordinary path computes the gradient and opens the step
             return False
+        o.begin_step()  # step number step_count + 1 is open; train_step steps the rest of the buffer
         self._counted = False
         self._table_stepped = True
         return True
