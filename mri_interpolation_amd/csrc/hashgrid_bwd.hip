@@ -260,7 +260,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       corner<D>(c, nb, h, w);
       const uint32_t slot = slot_of(h, size, magic, pow2);
       const uint32_t p = slot >> plan.log2_slots;
+#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 2)  // timing experiment: no placement atomics
+      const uint32_t pos = min(local_off[p] + ((threadIdx.x * 8 + nb) & 31), total - 1);
+#else
       const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+#endif
       stage[pos] = slot & slot_mask;
 #pragma unroll
       for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
@@ -276,6 +280,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
                                                      __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(max_bits + level, wg_max);
 
+#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 1)  // timing experiment: no copy-out (results are wrong)
+  return;
+#endif
   // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int p = wave; p < parts; p += kBinThreads / 64) {
@@ -624,6 +631,12 @@ __global__ __launch_bounds__(kAccThreads) void dense_and_accumulate_kernel(
     const AdamFuse ad) {
   __shared__ unsigned long long acc[kAccWords];
   const int b = blockIdx.x;
+#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 4)  // timing experiment: the records are not read
+  if (b >= dense_blocks) return;
+#endif
+#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 8)  // timing experiment: the dense levels are skipped
+  if (b < dense_blocks) return;
+#endif
   if (b < dense_blocks)
     dense_level_body<D, F>(acc, b, tab, dense, x, d_out, n, sl, sr, sf, max_bits, partial);
   else

@@ -249,8 +249,12 @@ class BatchPipeline:
         return coords[:n], target[:n]
 
     def produce_next(self):
-        """Queue the production of batch k+1 on the CURRENT stream."""
+        """Queue the production of batch k+1 on the CURRENT stream; returns its coordinates (the
+        tensor current() yields after advance()), so that a caller can start coordinate-only work of
+        the next step -- FusedStep counts the table-gradient records a step ahead."""
         self._produce(self.k + 1)
+        _, coords, _ = self.slots[(self.k + 1) % 2]
+        return coords[:self.sizes[(self.k + 1) % 2]]
 
     def advance(self):
         self.k += 1

@@ -114,7 +114,17 @@ class FusedStep:
         self.overlap_count = True
         self._side = None
         self._counted = False
-        self._bwd_ws = None  # this step's own scratch of the table gradient, see _hash_workspace
+        self._bwd_ws = [None, None]  # scratch of the table gradient, see _hash_workspace: two of them,
+        self._ws_index = 0           # so that the counting stage of batch k+1 can run during step k
+        self._ahead = None           # what was counted ahead: dict(ptr, n, ws, event)
+        self._count_event = None
+        self._batch_event = None
+        # Count batch k+1 during step k?  Pays when the decoder kernel starves the side stream: the
+        # 128-wide bf16-pipe kernel holds every CU's whole register file (512 threads x 250 VGPRs), the
+        # counting stage queued in its own step then ends ~30 us after it and the scatter waits
+        # (config 4: 0.572 -> 0.561 ms).  The 64-wide kernel leaves room, there the extra work beside
+        # the lookup only costs (config 2: 0.449 -> 0.458 ms).
+        self.count_ahead = self.use_tiny and self.layers[0].weight.shape[0] == 128
         # Fused decoder, optional: cut the batch in two slices and run the encoder of the second
         # on its own stream beside the decoder kernel of the first (the decoder leaves the VALU
         # and the texture path idle, the encoder needs no LDS).  Measured at BASELINE config 4:
@@ -267,15 +277,28 @@ class FusedStep:
         process never share it).  It is used on the main AND the side stream; when a larger batch
         needs a larger buffer, both streams are drained before the old one goes back to the
         allocator."""
+        return self._hash_workspace_at(self._ws_index, n)
+
+    def _hash_workspace_at(self, index: int, n: int):
         need = ops.backward_workspace_bytes(self.encoder.desc, n)
-        if self._bwd_ws is None or self._bwd_ws.numel() * 8 < need:
-            if self._bwd_ws is not None:
+        ws = self._bwd_ws[index]
+        if ws is None or ws.numel() * 8 < need:
+            if ws is not None:
                 torch.cuda.current_stream().synchronize()
                 if self._side is not None:
                     self._side.synchronize()
-            self._bwd_ws = torch.empty((need + 7) // 8, dtype=torch.int64,
-                                       device=self.flat.param.device)
-        return self._bwd_ws
+            ws = torch.empty((need + 7) // 8, dtype=torch.int64, device=self.flat.param.device)
+            self._bwd_ws[index] = ws
+        return ws
+
+    def _await_count(self):
+        """The main stream waits for the counting stage of THIS batch: the event recorded behind it when
+        it ran a step ahead, else everything queued on the side stream."""
+        if self._count_event is not None:
+            torch.cuda.current_stream().wait_event(self._count_event)
+            self._count_event = None
+        else:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def _overlap_plan(self, n: int) -> bool:
         """Prepare the slice counters of the side-by-side lookup for a batch of n rows."""
@@ -325,7 +348,7 @@ class FusedStep:
         (`reduce=False`: a micro-batch of an accumulation group that does not step)."""
         enc = self.encoder
         if self._counted:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self._await_count()
         counted, self._counted = self._counted, False
         ws = self._hash_workspace(coords.shape[0]) if self.bwd_method != 1 else None
         if self.grad_buckets <= 1 or not reduce or self.dp_mode == "reduce_scatter":
@@ -357,7 +380,7 @@ class FusedStep:
             return False
         enc = self.encoder
         if self._counted:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self._await_count()
         counted = self._counted
         t0, t1 = self._table_range()
         o = self.opt
@@ -514,19 +537,49 @@ class FusedStep:
         batches: first=True on the first one, step=True on the last, divisor=k on all.
         `side_work()` (e.g. BatchPipeline.produce_next) is queued where it overlaps the step:
         on the side stream behind the counting stage when there is one, else after Adam."""
+        if self._batch_event is not None:  # this batch was produced on the side stream during the last step
+            torch.cuda.current_stream().wait_event(self._batch_event)
+            self._batch_event = None
         if self.encoder is not None and self.overlap_count and self.bwd_method != 1:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=coords.device)
-            # after the coordinates exist and after the previous step's backward released the
-            # workspace (both are earlier work of the current stream)
+            # after the coordinates exist and after the previous step's backward released its
+            # workspace and batch buffer (all earlier work of the current stream)
             self._side.wait_stream(torch.cuda.current_stream())
-            ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side,
-                                          ws=self._hash_workspace(coords.shape[0]))
+            ahead, self._ahead = self._ahead, None
+            if ahead is not None and ahead["ptr"] == coords.data_ptr() and ahead["n"] == coords.shape[0]:
+                # this batch was counted during the previous step (below), into the other workspace
+                self._ws_index, self._count_event = ahead["ws"], ahead["event"]
+            else:
+                self._count_event = None
+                ops.hashgrid_backward_prepare(self.encoder.desc, coords, self.bwd_method, self._side,
+                                              ws=self._hash_workspace(coords.shape[0]))
             self._counted = True
             if side_work is not None:
-                with torch.cuda.stream(self._side):
-                    side_work()
-                side_work = None
+                work, side_work = side_work, None
+
+                def queue_side():
+                    with torch.cuda.stream(self._side):
+                        nxt = work()
+                    # the next step's forward pass reads what side_work produced: it waits for this
+                    # event (the wait for the counting stage no longer covers it once that runs ahead)
+                    self._batch_event = torch.cuda.Event()
+                    self._batch_event.record(self._side)
+                    if self.count_ahead and torch.is_tensor(nxt) and nxt.is_cuda:
+                        # `side_work` produced the NEXT batch and returned its coordinates: count it
+                        # now, into the workspace this step does not use.  The side stream is starved
+                        # while the decoder kernel holds every CU's registers, so a count queued in its
+                        # own step finished ~30 us after the decoder and the scatter waited for it; a
+                        # step ahead it has a whole step to finish
+                        other = 1 - self._ws_index
+                        ops.hashgrid_backward_prepare(self.encoder.desc, nxt, self.bwd_method,
+                                                      self._side,
+                                                      ws=self._hash_workspace_at(other, nxt.shape[0]))
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                        self._ahead = dict(ptr=nxt.data_ptr(), n=nxt.shape[0], ws=other, event=ev)
+
+                queue_side()
         if self.use_chain and self.chain_loss:
             self._pending = []
             self._chain_loss_pass(coords, target, first, divisor)

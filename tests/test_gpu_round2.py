@@ -800,3 +800,40 @@ def test_fused_table_adam_declines_what_it_cannot_serve(amd):
     for _ in range(2):
         a.train_step(x, y), b.train_step(x, y)
     assert a.opt.step_count == 2 and torch.equal(a.flat.param, b.flat.param)
+
+
+# ------------------------------------------------------------- the counting stage, one step ahead
+@pytest.mark.parametrize("shape,batch", [((40, 37, 29), 4096), ((16, 16, 16), 1000)])
+def test_counting_one_step_ahead_changes_nothing(amd, shape, batch):
+    """FusedStep counts the table-gradient records of batch k+1 during step k (second workspace, its
+    own event), as soon as BatchPipeline.produce_next has produced it: same parameters, bit for bit, as
+    counting inside the step -- over epoch ends (ragged last batch, a step without side work) too."""
+    vol = amd.datamodules.phantom_volume(shape).cpu().numpy()
+    runs = []
+    for ahead in (True, False):
+        torch.manual_seed(11)
+        net = amd.models.HashMLP(3, 8, 2, 14, 8, 64, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
+                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
+        step = amd.trainer.FusedStep(net, net.configure_optimizers())
+        assert step.count_ahead  # the default for the 128-wide decoder
+        step.count_ahead = ahead
+        ds = amd.datamodules.MriImage(volume=vol)
+        loader = amd.datamodules.DeviceLoader(ds, batch, shuffle=True, seed=3)
+        pipe = amd.datamodules.BatchPipeline(loader)
+        taken = 0
+        n_steps = 2 * len(loader) + 3
+        for k in range(n_steps):
+            x, y = pipe.current()
+            skip = k == len(loader)  # one step without side work: the next one must count for itself
+            if step._ahead is not None and step._ahead["ptr"] == x.data_ptr():
+                taken += 1
+            if skip:
+                pipe.produce_next()
+                step.train_step(x, y)
+            else:
+                step.train_step(x, y, pipe.produce_next)
+            pipe.advance()
+        torch.cuda.synchronize()
+        assert (taken > 0) == ahead and (not ahead or taken == n_steps - 2)
+        runs.append(step.flat.param.clone())
+    assert torch.equal(runs[0], runs[1])
