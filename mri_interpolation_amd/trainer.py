@@ -291,6 +291,10 @@ class FusedStep:
             self._bwd_ws[index] = ws
         return ws
 
+    def forget_ahead(self):
+        """Drop what was counted for a batch that will not be the next one (a new loader, say)."""
+        self._ahead = None
+
     def _await_count(self):
         """The main stream waits for the counting stage of THIS batch: the event recorded behind it when
         it ran a step ahead, else everything queued on the side stream."""
@@ -536,7 +540,10 @@ class FusedStep:
         returns the (device) loss scalar of this rank's batch.  Gradient accumulation over k
         batches: first=True on the first one, step=True on the last, divisor=k on all.
         `side_work()` (e.g. BatchPipeline.produce_next) is queued where it overlaps the step:
-        on the side stream behind the counting stage when there is one, else after Adam."""
+        on the side stream behind the counting stage when there is one, else after Adam.
+        Contract: if side_work() returns a CUDA tensor, that tensor IS the `coords` of the next
+        train_step call and is not modified in between -- with `count_ahead` its table-gradient
+        records are counted during this step (forget_ahead() drops such a count)."""
         if self._batch_event is not None:  # this batch was produced on the side stream during the last step
             torch.cuda.current_stream().wait_event(self._batch_event)
             self._batch_event = None
@@ -704,6 +711,7 @@ class Trainer:
                 and len(train_dataloaders) > 0:
             train_dataloaders.set_epoch(0)
             pipe = BatchPipeline(train_dataloaders)
+            self.fused.forget_ahead()  # a new pipeline: nothing counted earlier is about its batches
         for epoch in range(self.max_epochs):
             if pipe is None and hasattr(train_dataloaders, "set_epoch"):
                 train_dataloaders.set_epoch(epoch)
