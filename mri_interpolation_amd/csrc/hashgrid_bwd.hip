@@ -140,6 +140,19 @@ struct BinGeometry {
   static constexpr int corners = (1 << D) / tpc;                        // corners per thread
 };
 
+// Chunk of a count / scatter workgroup.  Workgroups go to the 8 XCDs round-robin by linear id, and
+// chunk c's run inside a bin is followed by chunk c + 1's: with chunk = blockIdx.x the two halves of
+// every shared 128-byte line would be written through two different L2s.  This map gives XCD k a
+// contiguous range of chunks, in dispatch order (a bijection of [0, gridDim.x) for any grid width).
+__device__ __forceinline__ int xcd_chunk() {
+#if defined(MRI_BWD_PLAIN_CHUNKS)
+  return blockIdx.x;
+#else
+  const int k = blockIdx.x & 7, j = blockIdx.x >> 3, q = gridDim.x >> 3, r = gridDim.x & 7;
+  return (k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q) + j;
+#endif
+}
+
 // ------------------------------------------------------------------------ 2. count / 4. scatter
 // One workgroup = (chunk of coords_per_block coordinates, level).  Both kernels walk the same
 // corners in the same way; `SCATTER` selects what is done with them.
@@ -195,10 +208,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   const bool pow2 = tab.pow2[level] != 0;
   const uint32_t slot_mask = (1u << plan.log2_slots) - 1u;
   const float* __restrict__ res = tab.res[level];
-  const int64_t i_begin = (int64_t)blockIdx.x * plan.coords_per_block;
+  const int chunk = xcd_chunk();
+  const int64_t i_begin = (int64_t)chunk * plan.coords_per_block;
   const int64_t i_end = min(n, i_begin + plan.coords_per_block);
   // per-(bin, chunk) tables, bin-major: entry (bin, chunk) at bin * chunks + chunk
-  const uint64_t row0 = (uint64_t)plan.bin_start[e] * chunks + blockIdx.x;
+  const uint64_t row0 = (uint64_t)plan.bin_start[e] * chunks + chunk;
 
   if (!SCATTER) {
     // count: how many corners of this chunk fall into each slice of the level
