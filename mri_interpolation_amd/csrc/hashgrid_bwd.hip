@@ -240,7 +240,20 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   }
 
   // scatter: this chunk's run inside every bin was fixed by the count + scan stages (no
-  // atomics, and the record order is the same on every run)
+  // atomics, and the record order is the same on every run).
+  // A workgroup lives for a chain of dependent global round trips (run tables -> scan -> coordinate
+  // and gradient -> records -> stores), and only three fit a CU: the coordinate's loads are issued
+  // first, so that they travel beside the run tables instead of behind them.
+  using G = BinGeometry<D, F>;
+  const int sub = threadIdx.x % G::tpc;  // this thread's share of the corners
+  const int64_t i = i_begin + threadIdx.x / G::tpc;  // one coordinate per thread (group)
+  const bool live = i < i_end;
+  const float* __restrict__ gl = d_out + (int64_t)level * sl;
+  float xi[D], g[F];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xi[d] = live ? x[i * D + d] : 0.0f;
+#pragma unroll
+  for (int f = 0; f < F; ++f) g[f] = live ? gl[i * sr + f * sf] : 0.0f;
   for (int p = threadIdx.x; p < parts; p += kBinThreads) {
     hist[p] = chunk_hist[row0 + (uint64_t)p * chunks];
     global_base[p] = offsets[plan.bin_start[e] + p] + chunk_base[row0 + (uint64_t)p * chunks];
@@ -254,18 +267,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
 
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
-  const float* __restrict__ gl = d_out + (int64_t)level * sl;
   float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
-  using G = BinGeometry<D, F>;
-  const int sub = threadIdx.x % G::tpc;
-  for (int64_t i = i_begin + threadIdx.x / G::tpc; i < i_end; i += kBinThreads / G::tpc) {
-    const Cell<D> c = locate<D>(x, i, res);
-    float g[F];
+  if (live) {
+    const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      g[f] = gl[i * sr + f * sf];
-      gmax = fmaxf(gmax, fabsf(g[f]));
-    }
+    for (int f = 0; f < F; ++f) gmax = fmaxf(gmax, fabsf(g[f]));
 #pragma unroll
     for (int q = 0; q < G::corners; ++q) {
       const int nb = sub * G::corners + q;
@@ -274,11 +280,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       corner<D>(c, nb, h, w);
       const uint32_t slot = slot_of(h, size, magic, pow2);
       const uint32_t p = slot >> plan.log2_slots;
-#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 2)  // timing experiment: no placement atomics
-      const uint32_t pos = min(local_off[p] + ((threadIdx.x * 8 + nb) & 31), total - 1);
-#else
       const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
-#endif
       stage[pos] = slot & slot_mask;
 #pragma unroll
       for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
@@ -294,9 +296,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
                                                      __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(max_bits + level, wg_max);
 
-#if defined(MRI_BWD_EXP) && (MRI_BWD_EXP & 1)  // timing experiment: no copy-out (results are wrong)
-  return;
-#endif
   // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int p = wave; p < parts; p += kBinThreads / 64) {
