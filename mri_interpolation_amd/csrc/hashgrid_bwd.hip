@@ -37,6 +37,19 @@
 namespace mri {
 namespace {
 
+// Per-workgroup time stamps of the scatter kernel for tools/bwd_segments.py (a tools-only build with
+// -DMRI_BWD_PROFILE; the shipped library has none of this).
+#ifdef MRI_BWD_PROFILE
+__device__ long long* g_bwd_profile = nullptr;
+#define BWDP(k)                                                                                   \
+  if (g_bwd_profile && threadIdx.x == 0)                                                          \
+    g_bwd_profile[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (k) == 0 || (k) == 7 \
+                                                                                 ? wall_clock64() \
+                                                                                 : clock64();
+#else
+#define BWDP(k)
+#endif
+
 #ifndef MRI_ACC_WORDS  // A/B builds: accumulators (and threads) of an accumulate workgroup
 #define MRI_ACC_WORDS 16384
 #endif
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   // A workgroup lives for a chain of dependent global round trips (run tables -> scan -> coordinate
   // and gradient -> records -> stores), and only three fit a CU: the coordinate's loads are issued
   // first, so that they travel beside the run tables instead of behind them.
+  BWDP(0) BWDP(1)
   using G = BinGeometry<D, F>;
   const int sub = threadIdx.x % G::tpc;  // this thread's share of the corners
   const int64_t i = i_begin + threadIdx.x / G::tpc;  // one coordinate per thread (group)
@@ -260,10 +274,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   }
   if (threadIdx.x == 0) wg_max = 0u;
   __syncthreads();
+  BWDP(2)
   if (threadIdx.x < 64) wave_exclusive_scan<kMaxParts / 64>(hist, local_off, parts);
   __syncthreads();
   for (int p = threadIdx.x; p < parts; p += kBinThreads) hist[p] = 0u;  // fill counters
   __syncthreads();
+  BWDP(3)
 
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
   if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
   __syncthreads();
+  BWDP(4)
   if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(max_bits + level, wg_max);
@@ -308,6 +325,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
         rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
     }
   }
+#ifdef MRI_BWD_PROFILE
+  BWDP(5)
+  __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+  BWDP(6) BWDP(7)
+#endif
 }
 
 // ----------------------------------------------------------------------------- 2b. chunk scan
@@ -1032,3 +1054,12 @@ extern "C" int mri_hashgrid_backward_adam(const mri_grid_desc* grid, const float
                        nullptr, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, 1, 0xffffffffu,
                        workspace, workspace_bytes_given, stream, &ad);
 }
+
+#ifdef MRI_BWD_PROFILE
+extern "C" int mri_debug_set_bwd_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(mri::g_bwd_profile), &device_buffer, sizeof(device_buffer)) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+#endif
