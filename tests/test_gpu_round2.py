@@ -803,11 +803,15 @@ def test_fused_table_adam_declines_what_it_cannot_serve(amd):
 
 
 # ------------------------------------------------------------- the counting stage, one step ahead
-@pytest.mark.parametrize("shape,batch", [((40, 37, 29), 4096), ((16, 16, 16), 1000)])
-def test_counting_one_step_ahead_changes_nothing(amd, shape, batch):
+@pytest.mark.parametrize("shape,batch,buckets", [((40, 37, 29), 4096, 0), ((16, 16, 16), 1000, 0),
+                                                 ((40, 37, 29), 4096, 4)])
+def test_counting_one_step_ahead_changes_nothing(amd, shape, batch, buckets):
     """FusedStep counts the table-gradient records of batch k+1 during step k (second workspace, its
     own event), as soon as BatchPipeline.produce_next has produced it: same parameters, bit for bit, as
-    counting inside the step -- over epoch ends (ragged last batch, a step without side work) too."""
+    counting inside the step -- over epoch ends (ragged last batch, a step without side work) too.
+    `buckets`: the data-parallel form of the step (gradients pre-divided by a world size of 2, the table
+    gradient in 4 level groups that each read the counted workspace, Adam per group), which is what
+    `bench.py --gpus N` runs."""
     vol = amd.datamodules.phantom_volume(shape).cpu().numpy()
     runs = []
     for ahead in (True, False):
@@ -817,6 +821,8 @@ def test_counting_one_step_ahead_changes_nothing(amd, shape, batch):
         step = amd.trainer.FusedStep(net, net.configure_optimizers())
         assert step.count_ahead  # the default for the 128-wide decoder
         step.count_ahead = ahead
+        if buckets:  # no process group: the reductions are no-ops, the code path is the N > 1 one
+            step.world, step.grad_buckets = 2, buckets
         ds = amd.datamodules.MriImage(volume=vol)
         loader = amd.datamodules.DeviceLoader(ds, batch, shuffle=True, seed=3)
         pipe = amd.datamodules.BatchPipeline(loader)
