@@ -243,6 +243,24 @@ int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, 
                              float* loss_out, float* y, int32_t overwrite, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* Encoder + decoder in ONE kernel (reference models.py:739-754, HashMLP.forward = encoder -> ReLU MLP,
+ * with F.mse_loss and the decoder's autograd): the decoder's workgroups look the features of their
+ * next row tile up themselves while the matrix pipe works on the current one, so the lookup kernel
+ * and the feature block (2 x 4 L F bytes per coordinate) disappear.  Same arithmetic as
+ * mri_hashgrid_forward followed by mri_tiny_mlp_train[_overwrite]: bit-identical loss, gradients and
+ * d_enc.  Grids with n_features = 2, dim 2..4, <= 16 levels, < 2^29 table rows; hidden 64 or 128
+ * (mri_hash_tiny_mlp_supported, else MRI_ERR_UNSUPPORTED).  coords (n, dim) row-major; d_enc
+ * (2 L, d_enc_ld) feature-major = dLoss / d features, the input of mri_hashgrid_backward; workspace as
+ * mri_tiny_mlp_workspace_bytes(2 L, hidden, n). */
+int mri_hash_tiny_mlp_supported(const mri_grid_desc* grid, int32_t hidden);
+int mri_hash_tiny_mlp_train(const mri_grid_desc* grid, const float* table, const float* coords,
+                            const float* target, int64_t n, int32_t hidden, const float* w1,
+                            const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                            float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_enc,
+                            int64_t d_enc_ld, float* loss_out, float* y, int32_t overwrite,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Gradient w.r.t. the COORDINATES: the reference detaches only the integer part of x * res
  * (encoding.py:111-113), so autograd carries d out / d x through the interpolation weights:
  * d_x[i][d] = res_d * sum over levels and corners of (+-1) prod_{e != d} w_e * <d_out, row>.

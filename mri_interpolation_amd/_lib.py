@@ -66,6 +66,8 @@ SIGNATURES = {
                            _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_tiny_mlp_train_overwrite": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "mri_hash_tiny_mlp_train": [C.POINTER(GridDesc), _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F,
+                                _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32, _P, _I64, _P],
     "mri_hashgrid_backward_input": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
     "mri_hashgrid_forward_signal": [C.POINTER(GridDesc), _P, _I64, _P, _P, _I64, _I64, _P, _P],
     "mri_tiny_mlp_train_overlapped": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
@@ -91,6 +93,7 @@ INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), 
                  "mri_hashgrid_forward_signal_blocks": [C.POINTER(GridDesc), _I64],
                  "mri_tiny_mlp_round_rows": [_I32, _I32, _I64]}
 INT_GETTERS = {"mri_tiny_mlp_supported": [_I32, _I32, _I32],
+               "mri_hash_tiny_mlp_supported": [C.POINTER(GridDesc), _I32],
                "mri_siren_supported": [_I32, _I32, _I32, _I32]}  # return a plain value, not a status
 
 _lib = None

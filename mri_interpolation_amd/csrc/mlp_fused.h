@@ -1,6 +1,7 @@
 // Shared by the fused tiny-MLP kernels (mlp_fused.hip: f32 MFMA; mlp_x3.hip: bf16x3 MFMA).
 #pragma once
 #include "common.h"
+#include "hashgrid_common.h"
 
 namespace mri {
 
@@ -28,6 +29,16 @@ struct FusedArgs {
 };
 
 
+// mlp_x3.hip, optional: the decoder looks its input features up in the hash grid itself (F = 2, so
+// k_in = 2 n_levels <= 32): no lookup kernel, the features never reach HBM.  FusedArgs::x is unused then.
+struct EncodeArgs {
+  const float* coords = nullptr;  // (n, dim) row-major
+  const float* table = nullptr;   // all levels, (rows, 2); rows < 2^29 (32-bit byte offsets)
+  LevelTab tab;
+  int n_levels = 0;
+  int dim = 0;                    // 0: features come from FusedArgs::x
+};
+
 // slab layout (floats): dW1 [H*k_in] | db1 [H] | dW2 [H*H] | db2 [H] | dW3 [H] | db3 [1] | loss [1]
 __host__ __device__ inline int slab_floats(int H, int k_in) { return H * k_in + H + H * H + H + H + 2; }
 
@@ -37,5 +48,7 @@ bool x3_supported(int k_in, int hidden);
 bool x3_addressable(const FusedArgs& a);  // 32-bit lane offsets inside x / dx
 int x3_blocks(int64_t n);
 int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, hipStream_t st);
+bool x3_encode_supported(int dim, int n_features, int n_levels, int hidden);
+int launch_tiny_mlp_x3_encoded(const FusedArgs& a, const EncodeArgs& e, int hidden, int blocks, hipStream_t st);
 
 }  // namespace mri

@@ -1090,6 +1090,61 @@ extern "C" int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const floa
                              loss_out, y, workspace, workspace_bytes, stream);
 }
 
+extern "C" int mri_hash_tiny_mlp_supported(const mri_grid_desc* grid, int32_t hidden) {
+  if (!grid || !options().mlp_x3) return 0;
+  int64_t rows = 0;
+  for (int l = 0; l < grid->n_levels && l < MRI_MAX_LEVELS; ++l)
+    rows = std::max<int64_t>(rows, (int64_t)grid->table_offset[l] + grid->table_size[l]);
+  return x3_encode_supported(grid->dim, grid->n_features, grid->n_levels, hidden) && rows < (1ll << 29) ? 1 : 0;
+}
+
+extern "C" int mri_hash_tiny_mlp_train(const mri_grid_desc* grid, const float* table, const float* coords,
+                                       const float* target, int64_t n, int32_t hidden, const float* w1,
+                                       const float* b1, const float* w2, const float* b2, const float* w3,
+                                       const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                       float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_enc,
+                                       int64_t d_enc_ld, float* loss_out, float* y, int32_t overwrite,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+  MRI_REQUIRE(grid != nullptr, "grid descriptor is NULL");
+  MRI_REQUIRE(mri_hash_tiny_mlp_supported(grid, hidden),
+              "encoder (dim %d, %d levels x %d features) + decoder %d: no one-kernel form "
+              "(mri_hash_tiny_mlp_supported)", grid->dim, grid->n_levels, grid->n_features, hidden);
+  MRI_REQUIRE(n >= 0 && grad_divisor > 0.f, "bad n / grad_divisor");
+  if (n == 0) return MRI_OK;
+  const int k_in = 2 * grid->n_levels;
+  MRI_REQUIRE(table && coords && target && w1 && b1 && w2 && b2 && w3 && b3, "NULL device pointer");
+  MRI_REQUIRE(d_w1 && d_b1 && d_w2 && d_b2 && d_w3 && d_b3 && loss_out, "NULL gradient pointer");
+  MRI_REQUIRE(!d_enc || d_enc_ld >= n, "d_enc rows are %lld apart, batch of %lld", (long long)d_enc_ld,
+              (long long)n);
+  const int slab = slab_floats(hidden, k_in);
+  const int blocks = x3_blocks(n);
+  MRI_REQUIRE(workspace && workspace_bytes >= (int64_t)blocks * slab * 4,
+              "needs a workspace of %lld bytes (mri_tiny_mlp_workspace_bytes)", (long long)blocks * slab * 4);
+  FusedArgs a{};
+  a.target = target;
+  a.w1 = w1, a.b1 = b1, a.w2 = w2, a.b2 = b2, a.w3 = w3, a.b3 = b3;
+  a.y = y, a.dx = d_enc, a.partial = static_cast<float*>(workspace);
+  a.n = n, a.ld = d_enc ? d_enc_ld : n, a.k_in = k_in;
+  MRI_REQUIRE(x3_addressable(a), "d_enc block beyond 32-bit lane offsets");
+  a.grad_scale = (float)(2.0 / ((double)n * (double)grad_divisor));
+  a.inv_n = (float)(1.0 / (double)n);
+  EncodeArgs e{};
+  e.coords = coords, e.table = table, e.tab = make_tab(grid), e.n_levels = grid->n_levels, e.dim = grid->dim;
+  if (int rc = launch_tiny_mlp_x3_encoded(a, e, hidden, blocks, (hipStream_t)stream)) return rc;
+  ReduceArgs r{};
+  r.partial = a.partial, r.slabs = blocks, r.slab = slab, r.n_seg = 7, r.overwrite = overwrite ? 1 : 0;
+  const int lens[7] = {hidden * k_in, hidden, hidden * hidden, hidden, hidden, 1, 1};
+  float* dsts[7] = {d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, loss_out};
+  int off = 0;
+  for (int g = 0; g < 7; ++g) {
+    r.seg_begin[g] = off, r.seg_len[g] = lens[g], r.dst[g] = dsts[g];
+    off += lens[g];
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 64)), dim3(256), 0,
+                     (hipStream_t)stream, r);
+  return check_launch("slab_reduce_kernel");
+}
+
 extern "C" int64_t mri_tiny_mlp_round_rows(int32_t k_in, int32_t hidden, int64_t n) {
   // rows one round of the training kernel's workgroups consumes (the team kernel only)
   if (!supported(k_in, hidden, 1) || hidden != 128 || n < 1) return 0;

@@ -72,6 +72,8 @@ struct __attribute__((aligned(16))) X3Smem {
   float ypart[8][kX3Rows];
   float tgt[2][kX3Rows];
   float b1[kX3H], b2[kX3H], w3[kX3H];  // read per tile (registers are the scarce resource here)
+  float gc[2][kX3Rows][4];             // gather mode: coordinates of the next two tiles
+  float pa[kX3Threads][2];             // gather mode: a thread's partial sums, parked between two segments
 };
 
 // Three-term fragments at byte offset `off` of an image whose terms are TERM bytes apart.
@@ -113,8 +115,13 @@ __device__ __forceinline__ float sum_groups(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-template <bool TRAIN, int U, int H>
-__global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a) {
+template <bool TRAIN, int U, int H, int GD = 0>
+__global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a, const EncodeArgs e) {
+  // GD > 0 (gather mode, training, U = 1): the input features are looked up in the GD-dimensional hash
+  // grid `e` by the thread that stages them -- thread (row tid & 31, level tid >> 5) of the staging map
+  // below owns exactly one (coordinate, level) pair and its two features -- see "gather mode" below.
+  constexpr bool GATHER = GD > 0;
+  static_assert(!GATHER || (TRAIN && U == 1), "gather mode: the 8-wave training kernel");
   // U = strips of 16 hidden units per wave: 1 -> 8 waves (two per SIMD, 256 registers each),
   // 2 -> 4 waves (one per SIMD, 512 registers; every activation fragment feeds two strips).
   // H = 128: wave w owns strip w (U = 1) for both 16-row halves of the tile.  H = 64 (U = 1): four
@@ -270,6 +277,111 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     if (TRAIN && skp == 0) sm.tgt[buf][sb] = xt;
   };
 
+  // ---- gather mode.  The (coordinate, level) pair of this thread needs 2^GD table rows of 8 bytes.  They
+  // are fetched in two batches, corners with the lower (xc = 0) and the upper (xc = 1) vertex on axis 0
+  // -- the partial sums and their order are those of hashgrid_fwd_pair_kernel, so the features are
+  // bit-identical to the lookup kernel's -- and each batch spends at least a segment in flight:
+  //   S5(i): take batch 1 of tile i+1 -> features -> x image;      issue batch 0 of tile i+2
+  //   S7(i): take batch 0 of tile i+2 -> partial sums, parked;     issue batch 1 of tile i+2
+  // What stays in registers between the segments is the batch in flight; the coordinates of the two
+  // upcoming tiles live in LDS (sm.gc, written a barrier before their first use), level constants
+  // come from the kernel arguments through scalar loads at each use.
+  constexpr int NB = GATHER ? 1 << (GD - 1) : 1;  // corners per batch
+  float2 gv[NB];
+  float gcr = 0.f;  // a coordinate of tile i+3 on its way to sm.gc (threads < 32 GD)
+  struct Lvl {
+    float res[GATHER ? GD : 1];
+    uint32_t size, magic, rows;
+    bool pow2, on;
+  };
+  auto level_consts = [&]() {
+    Lvl L;
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));  // re-derived per use: nothing of this is kept across segments
+    const int wu = __builtin_amdgcn_readfirstlane(t_op >> 6);
+    const int la = min(2 * wu, e.n_levels - 1), lb = min(2 * wu + 1, e.n_levels - 1);
+    const bool hi = (t_op & 32) != 0;
+#pragma unroll
+    for (int d = 0; d < (GATHER ? GD : 1); ++d) L.res[d] = hi ? e.tab.res[lb][d] : e.tab.res[la][d];
+    L.size = hi ? e.tab.size[lb] : e.tab.size[la];
+    L.magic = hi ? e.tab.magic[lb] : e.tab.magic[la];
+    L.pow2 = (hi ? e.tab.pow2[lb] : e.tab.pow2[la]) != 0;
+    L.rows = (uint32_t)(hi ? e.tab.offset[lb] : e.tab.offset[la]);
+    L.on = (t_op >> 5) < e.n_levels;
+    return L;
+  };
+  auto g_cell = [&](int cb, const Lvl& L) {
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    float p[GATHER ? GD : 1];
+#pragma unroll
+    for (int d = 0; d < (GATHER ? GD : 1); ++d) p[d] = sm.gc[cb][t_op & 31][d];
+    return locate<(GATHER ? GD : 1)>(p, 0, L.res);
+  };
+  auto g_issue = [&](int cb, int xc) {
+    if constexpr (GATHER) {
+      const Lvl L = level_consts();
+      const Cell<GD> c = g_cell(cb, L);
+      const float2* __restrict__ rows2 = reinterpret_cast<const float2*>(e.table);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        uint32_t h;
+        float wgt;
+        corner<GD>(c, (nb << 1) | xc, h, wgt);
+        gv[nb] = rows2[L.rows + slot_of(h, L.size, L.magic, L.pow2)];  // uniform base + 32-bit offset
+      }
+    }
+  };
+  auto g_take = [&](int cb, int xc, float& p0, float& p1) {
+    if constexpr (GATHER) {
+      const Lvl L = level_consts();
+      const Cell<GD> c = g_cell(cb, L);
+      p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        uint32_t h;
+        float wgt;
+        corner<GD>(c, (nb << 1) | xc, h, wgt);
+        p0 = p0 + gv[nb].x * wgt;
+        p1 = p1 + gv[nb].y * wgt;
+      }
+    }
+  };
+  // coordinates of the tile at m0: global -> register (threads < 32 GD, one float each, contiguous)
+  auto g_coords_load = [&](int64_t m0) {
+    if constexpr (GATHER) {
+      int t_op = tid;
+      asm volatile("" : "+v"(t_op));
+      const bool live = t_op < 32 * GD && t_op / GD < a.n - m0;
+      gcr = live ? (e.coords + m0 * GD)[t_op] : 0.f;
+    }
+  };
+  auto g_coords_store = [&](int cb) {
+    if constexpr (GATHER) {
+      int t_op = tid;
+      asm volatile("" : "+v"(t_op));
+      if (t_op < 32 * GD) sm.gc[cb][t_op / GD][t_op % GD] = gcr;
+    }
+  };
+  // batch 1 of the tile staged next has landed: features = parked batch-0 sums + these -> x image
+  auto g_finish = [&](int cb, int xbuf, int64_t m0, float pa0, float pa1) {
+    if constexpr (GATHER) {
+      float pb0, pb1;
+      g_take(cb, 1, pb0, pb1);
+      int t_op = tid;
+      asm volatile("" : "+v"(t_op));
+      const bool on = (t_op >> 5) < e.n_levels && (t_op & 31) < a.n - m0;
+      xv[0][0] = on ? pa0 + pb0 : 0.f;  // as hashgrid_fwd_pair_kernel: own partial sum + the partner's
+      xv[0][1] = on ? pb1 + pa1 : 0.f;
+      store_x(xbuf);
+    }
+  };
+  auto g_target = [&](int64_t m0) {
+    int t_op = tid;
+    asm volatile("" : "+v"(t_op));
+    xt = (t_op < 32 && t_op < a.n - m0) ? (a.target + m0)[t_op] : 0.f;
+  };
+
   // Fragments are fetched one group ahead of the MFMAs that use them, into the other half of a
   // two-entry buffer (pinned with sched_barriers: left alone, hipcc waits for each read right in
   // front of its MFMA and exposes the LDS latency two or three times per six MFMAs).
@@ -316,9 +428,34 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   const int64_t tiles = (a.n + kX3Rows - 1) / kX3Rows;
   const int64_t stride = gridDim.x;
   int buf = 0;
-  load_x((int64_t)blockIdx.x * kX3Rows);
-  store_x(0);
-  if (blockIdx.x + stride < tiles) load_x((blockIdx.x + stride) * kX3Rows);  // stays in registers
+  if constexpr (GATHER) {
+    const int64_t t0 = blockIdx.x, t1 = t0 + stride, t2 = t1 + stride;
+    g_coords_load(t0 * kX3Rows);
+    g_coords_store(0);
+    if (t1 < tiles) {
+      g_coords_load(t1 * kX3Rows);
+      g_coords_store(1);
+    }
+    __syncthreads();
+    float pa0, pa1;
+    g_issue(0, 0);
+    g_take(0, 0, pa0, pa1);
+    g_issue(0, 1);
+    g_target(t0 * kX3Rows);
+    g_finish(0, 0, t0 * kX3Rows, pa0, pa1);
+    if (t1 < tiles) {  // loop invariant: batch 1 of the next tile in flight, its batch-0 sums parked
+      g_issue(1, 0);
+      g_take(1, 0, pa0, pa1);
+      *reinterpret_cast<float2*>(&sm.pa[tid][0]) = make_float2(pa0, pa1);
+      g_issue(1, 1);
+      g_target(t1 * kX3Rows);
+    }
+    if (t2 < tiles) g_coords_load(t2 * kX3Rows);  // -> sm.gc[0] in S2 of the first tile
+  } else {
+    load_x((int64_t)blockIdx.x * kX3Rows);
+    store_x(0);
+    if (blockIdx.x + stride < tiles) load_x((blockIdx.x + stride) * kX3Rows);  // stays in registers
+  }
   __syncthreads();
   layer1(0);
   X3P_BEGIN
@@ -338,6 +475,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     };
     if (!TRAIN) stage_next();
     X3P_SYNC(0)  // B0: h1 of this tile complete (and, inference, x of the next staged)
+    if (GATHER && has_next2) g_coords_store(buf);  // coordinates of tile i+2 (read from S5 on: behind B2)
     // ---- S2: h2 = relu(h1 W2^T + b2); this wave's share of y ---------------------------------------
     float h2[U][TL][4];
     {
@@ -430,7 +568,18 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       if (has_next) layer1(buf ^ 1);  // x(i+1) was staged before B0
       continue;
     }
-    stage_next();
+    if constexpr (GATHER) {
+      if (has_next) {
+        const float2 pa = *reinterpret_cast<const float2*>(&sm.pa[tid][0]);
+        g_finish(buf ^ 1, buf ^ 1, (tile + stride) * kX3Rows, pa.x, pa.y);
+      }
+      if (has_next2) {
+        g_issue(buf, 0);
+        g_target((tile + 2 * stride) * kX3Rows);
+      }
+    } else {
+      stage_next();
+    }
     // ---- S5b: dW2[units][:] += dz2^T h1 (contracts the 32 rows: both operands transposed reads; the
     //      dz2 columns are this wave's own stores above, and a wave's LDS operations execute in order)
     {
@@ -503,6 +652,15 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       }
     }
     X3P_SYNC(4)  // B4
+    if constexpr (GATHER) {
+      if (has_next2) {
+        float pa0, pa1;
+        g_take(buf, 0, pa0, pa1);
+        *reinterpret_cast<float2*>(&sm.pa[tid][0]) = make_float2(pa0, pa1);
+        g_issue(buf, 1);
+      }
+      if (tile + 3 * stride < tiles) g_coords_load((tile + 3 * stride) * kX3Rows);
+    }
     // ---- S7: dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each); layer 1 of the next tile ---
     if (a.dx && w < 4) {
       const int kt = w & 1, bt = w >> 1;
@@ -813,19 +971,41 @@ int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, h
     hipLaunchKernelGGL(tiny_mlp_x3_infer_kernel, dim3(ib), dim3(kX3Threads), 0, st, a);
     return check_launch("tiny_mlp_x3_infer_kernel");
   }
+  const EncodeArgs none{};
   if (hidden == 64 && train)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (hidden == 64)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (train && wide)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a, none);
   else if (train)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (wide)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a, none);
   else
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a);
+    hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   return check_launch("tiny_mlp_x3_kernel");
+}
+
+bool x3_encode_supported(int dim, int n_features, int n_levels, int hidden) {
+  return n_features == 2 && dim >= 2 && dim <= 4 && n_levels >= 1 && 2 * n_levels <= 32 &&
+         (hidden == 128 || hidden == 64);
+}
+
+int launch_tiny_mlp_x3_encoded(const FusedArgs& a, const EncodeArgs& e, int hidden, int blocks, hipStream_t st) {
+#define MRI_X3_ENC(HH, DD) \
+  hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, HH, DD>), dim3(blocks), dim3(kX3Threads), 0, st, a, e)
+  if (hidden == 128) {
+    if (e.dim == 2) MRI_X3_ENC(128, 2);
+    else if (e.dim == 3) MRI_X3_ENC(128, 3);
+    else MRI_X3_ENC(128, 4);
+  } else {
+    if (e.dim == 2) MRI_X3_ENC(64, 2);
+    else if (e.dim == 3) MRI_X3_ENC(64, 3);
+    else MRI_X3_ENC(64, 4);
+  }
+#undef MRI_X3_ENC
+  return check_launch("tiny_mlp_x3_kernel (encoded)");
 }
 
 }  // namespace mri

@@ -459,6 +459,32 @@ def tiny_mlp_train(x_fm, target, params, grads, loss_out, d_x=None, y=None,
     return loss_out
 
 
+def hash_tiny_mlp_supported(desc: GridDesc, hidden: int) -> bool:
+    """Is there a one-kernel form of encoder + decoder step for this grid and decoder width?"""
+    return bool(_lib.load().mri_hash_tiny_mlp_supported(C.byref(desc), int(hidden)))
+
+
+def hash_tiny_mlp_train(desc: GridDesc, table, coords, target, params, grads, loss_out, d_enc,
+                        y=None, grad_divisor: float = 1.0, overwrite: bool = False):
+    """hashgrid_forward + tiny_mlp_train in one kernel (mri_hash_tiny_mlp_train): the decoder looks the
+    features up itself; `d_enc` (2 L, ld >= n) feature-major receives dLoss / d features."""
+    (w1, b1), (w2, b2), (w3, b3) = params
+    (g1, gb1), (g2, gb2), (g3, gb3) = grads
+    _gpu(table, coords, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_enc, y)
+    coords = _rowmajor(coords).contiguous()
+    n = coords.shape[0]
+    k_in = 2 * desc.n_levels
+    if d_enc is not None and (d_enc.shape[0] != k_in or d_enc.stride(1) != 1 or d_enc.shape[1] < n):
+        raise ValueError("d_enc must be a feature-major (2 L, >= n) block")
+    ws = _tiny_workspace(k_in, w1.shape[0], n, coords.device)
+    _lib.call("mri_hash_tiny_mlp_train", C.byref(desc), _ptr(table), _ptr(coords), _ptr(target), n,
+              w1.shape[0], _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3),
+              float(grad_divisor), _ptr(g1), _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3),
+              _ptr(d_enc), d_enc.stride(0) if d_enc is not None else n, _ptr(loss_out), _ptr(y),
+              1 if overwrite else 0, _ptr(ws), ws.numel() * 4, _stream())
+    return loss_out
+
+
 def tiny_mlp_train_slice(x_fm, target, col_offset: int, n: int, params, grads, loss_out, d_x,
                          grad_divisor: float = 1.0, overwrite: bool = False):
     """tiny_mlp_train for columns [col_offset, col_offset + n) of the feature-major batch block

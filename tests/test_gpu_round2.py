@@ -843,3 +843,45 @@ def test_counting_one_step_ahead_changes_nothing(amd, shape, batch, buckets):
         assert (taken > 0) == ahead and (not ahead or taken == n_steps - 2)
         runs.append(step.flat.param.clone())
     assert torch.equal(runs[0], runs[1])
+
+
+# --------------------------------------------------- encoder + decoder in one kernel (gather mode)
+@pytest.mark.parametrize("dim,levels,log2t,hidden,n", [(3, 16, 19, 128, 1 << 18), (3, 16, 15, 128, 70001),
+                                                       (3, 16, 15, 64, 50000), (3, 5, 12, 128, 33),
+                                                       (2, 8, 14, 64, 4097), (4, 16, 14, 128, 20000),
+                                                       (3, 16, 15, 128, 31), (3, 16, 15, 128, 8192 * 3 + 5)])
+def test_one_kernel_encoder_decoder_equals_the_two_kernel_step(amd, dim, levels, log2t, hidden, n):
+    """mri_hash_tiny_mlp_train (the decoder's workgroups look their features up themselves) against
+    mri_hashgrid_forward + mri_tiny_mlp_train: loss, predictions, decoder gradients and d_enc bit for bit
+    (same partial sums in the same order) -- full tiles, ragged tails, fewer than 16 levels, batches of
+    less than one tile and of several rounds of the workgroups."""
+    from mri_interpolation_amd import ops
+    torch.manual_seed(dim * 1000 + levels + n)
+    enc = amd.encoding.MultiResHashGrid(dim, levels, 2, log2t, 16, 512).cuda()
+    with torch.no_grad():
+        enc.table.uniform_(-0.5, 0.5)
+    assert ops.hash_tiny_mlp_supported(enc.desc, hidden)
+    k_in = 2 * levels
+    x = torch.rand(n, dim, device="cuda")
+    t = torch.rand(n, device="cuda")
+    mk = lambda *s_: torch.randn(*s_, device="cuda")  # noqa: E731
+    params = [(mk(hidden, k_in) / k_in ** 0.5, mk(hidden) * 0.1), (mk(hidden, hidden) / hidden ** 0.5, mk(hidden) * 0.1),
+              (mk(1, hidden) / hidden ** 0.5, mk(1) * 0.1)]
+
+    def fresh():
+        return ([tuple(torch.zeros_like(p) for p in wb) for wb in params], torch.zeros(1, device="cuda"),
+                torch.full((k_in, n), 7.0, device="cuda"), torch.empty(n, device="cuda"))
+    g_a, loss_a, d_a, y_a = fresh()
+    feats = torch.empty(k_in, n, device="cuda")
+    ops.hashgrid_forward(enc.desc, x, enc.table.data, out=feats, feature_major=True)
+    ops.tiny_mlp_train(feats, t, params, g_a, loss_a, d_x=d_a, y=y_a, overwrite=True)
+    g_b, loss_b, d_b, y_b = fresh()
+    ops.hash_tiny_mlp_train(enc.desc, enc.table.data, x, t, params, g_b, loss_b, d_b, y=y_b, overwrite=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_b)
+    assert torch.equal(loss_a, loss_b)
+    assert torch.equal(d_a, d_b)
+    for wa, wb in zip(g_a, g_b):
+        for ga, gb in zip(wa, wb):
+            assert torch.equal(ga, gb)
+
