@@ -259,8 +259,8 @@ def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--psnr-steps", type=int, default=None,
                     help="total training steps before the PSNR evaluation (0 = skip; default 2000, "
