@@ -113,6 +113,46 @@ __device__ __forceinline__ long long to_fixed(float v, float scale_hi) {
   return ((long long)hi << 32) + ((long long)lo << 1);
 }
 
+// Packed records (F = 2): ONE 8-byte word = 13-bit slot | two values of 3 + 22 bits.  A value v = w g is
+// stored as a 22-bit signed integer m and a 3-bit class c: v ~ m 2^-(es0 + 4 c), es0 = 16 - E for a level
+// whose max |g| < 2^(E+1) (known BEFORE the scatter: level_absmax pre-pass), c = min((E + 4 - exponent(v)) / 4, 7).
+// Class 0 is for |v| >= 2^(E+1): a coordinate outside the grid has interpolation weights up to 2 per axis
+// (the reference extrapolates, encoding.py:113), so |w g| < 2^D max|g| <= 2^(E+5) for D <= 4.  Classes 1..7:
+// a value keeps 18 to 21 significant bits whatever its size down to 2^-24 of the level's maximum (below
+// that the resolution stays 2^(E-44); what is smaller than 2^(E-45) becomes 0), and values near the
+// maximum are within 2^-22 of it of their f32 value.  The integer sum of the records is exact, so the
+// gradient stays bitwise reproducible; per record it is rounded to those 18-21 bits (the tests' 1e-5 is
+// on the level's largest gradient, where the rounding is 2.4e-7).  Plain 24-bit fixed point would lose
+// every contribution below 2^-23 of the level's maximum, which Adam, scale-free per parameter, still sees.
+template <int F>
+constexpr bool kPackedRecords = (F == 2);
+static_assert(kAccWords / 2 <= 8192, "packed records hold the slot within a slice in 13 bits");
+__device__ __forceinline__ int level_E(uint32_t max_bits) { return (int)((max_bits >> 23) & 255u) - 127; }
+__device__ __forceinline__ int rec_exponent(uint32_t max_bits) {  // es0
+  return max(-126, min(16 - level_E(max_bits), 98));
+}
+__device__ __forceinline__ uint32_t pack_value(float v, int E, int es0) {  // -> c (3 bits) << 22 | m (22 bits)
+  const int ev = (int)((__float_as_uint(v) >> 23) & 255u) - 127;
+  const int c = min(max(E + 4 - ev, 0) >> 2, 7);
+  const float scale = __uint_as_float((uint32_t)(es0 + 4 * c + 127) << 23);  // 2^(es0 + 4 c), <= 2^126
+  const int m = max(-2097151, min(__float2int_rn(v * scale), 2097151));
+  return ((uint32_t)c << 22) | ((uint32_t)m & 0x3fffffu);
+}
+__device__ __forceinline__ uint2 pack_record(uint32_t slot, float v0, float v1, int E, int es0) {
+  const uint32_t a = pack_value(v0, E, es0), b = pack_value(v1, E, es0);  // 25 bits each
+  // lo: slot [12:0] | c0 [15:13] | m0 low half [31:16];  hi: m0 high 6 bits [5:0] | c1 [8:6] | m1 [30:9]
+  return make_uint2((slot & 0x1fffu) | ((a >> 22) << 13) | (a << 16),
+                    ((a >> 16) & 0x3fu) | ((b >> 22) << 6) | ((b & 0x3fffffu) << 9));
+}
+// -> slot and the two values as integers in units of 2^-(es0 + 28) ... shifted by the caller: m and class
+__device__ __forceinline__ void unpack_record(uint32_t lo, uint32_t hi, uint32_t& slot, int& m0, int& c0,
+                                              int& m1, int& c1) {
+  slot = lo & 0x1fffu;
+  c0 = (lo >> 13) & 7, c1 = (hi >> 6) & 7;
+  m0 = (int)(__builtin_amdgcn_alignbit(hi, lo, 16) << 10) >> 10;  // 22 bits from bit 16, sign-extended
+  m1 = (int)(hi << 1) >> 10;                                       // bits 9..30
+}
+
 // Exclusive prefix sum of `count` <= 64 * kPerLane values in LDS by ONE wave (call from wave 0):
 // out[i] = sum of in[0..i), out[count] = total.
 template <int kPerLane>
@@ -146,6 +186,7 @@ __device__ __forceinline__ void wave_exclusive_scan(const uint32_t* in, uint32_t
 // their 16 corners are then split over 2 (4) threads instead of leaving half the workgroup idle
 template <int D, int F>
 struct BinGeometry {
+  static constexpr int rec_words = kPackedRecords<F> ? 2 : 1 + F;  // staged words per record
   static constexpr int per_coord = (1 << D) * (1 + F);
   static constexpr int coords = kStageWords / per_coord / 64 * 64 < kBinThreads
                                     ? kStageWords / per_coord / 64 * 64 : kBinThreads;
@@ -180,7 +221,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
-  __shared__ uint32_t stage[SCATTER ? kStageWords : 1];
+  // (packed records: 8 instead of 12 bytes per corner -> 32 KiB, four workgroups per CU)
+  __shared__ __attribute__((aligned(16))) uint32_t stage[SCATTER ? (kPackedRecords<F> ? kStageWords * 2 / 3 : kStageWords) : 1];
   __shared__ uint32_t wg_max;
 
   const int e = blockIdx.y;
@@ -283,46 +325,77 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
 
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
-  float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
-  if (live) {
-    const Cell<D> c = locate<D>(xi, 0, res);
-#pragma unroll
-    for (int f = 0; f < F; ++f) gmax = fmaxf(gmax, fabsf(g[f]));
-#pragma unroll
-    for (int q = 0; q < G::corners; ++q) {
-      const int nb = sub * G::corners + q;
-      uint32_t h;
-      float w;
-      corner<D>(c, nb, h, w);
-      const uint32_t slot = slot_of(h, size, magic, pow2);
-      const uint32_t p = slot >> plan.log2_slots;
-      const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
-      stage[pos] = slot & slot_mask;
-#pragma unroll
-      for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
-  // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
-  // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
-  if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
-  __syncthreads();
-  BWDP(4)
-  if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(max_bits + level, wg_max);
-
-  // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int p = wave; p < parts; p += kBinThreads / 64) {
-    const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
-    const uint64_t dst = (uint64_t)global_base[p];
-    for (uint32_t k = lane; k < cnt; k += 64) {
-      rec_slot[dst + k] = (uint16_t)stage[lo + k];
+  if constexpr (kPackedRecords<F>) {
+    // one 8-byte word per record (pack_record): one scattered LDS store here, one read and ONE global
+    // store in the copy-out, one load in the accumulate kernel -- a third of the 2 + 4 + 4-byte form's
+    // LDS conflict cycles and store instructions, which is where this kernel's time goes (4.2)
+    const uint32_t mb = max_bits[level];  // complete: level_absmax ran before this kernel
+    const int E = level_E(mb), es0 = rec_exponent(mb);
+    uint2* __restrict__ stage2 = reinterpret_cast<uint2*>(stage);
+    if (live) {
+      const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
-      for (int f = 0; f < F; ++f)
-        rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
+      for (int q = 0; q < G::corners; ++q) {
+        uint32_t h;
+        float w;
+        corner<D>(c, sub * G::corners + q, h, w);
+        const uint32_t slot = slot_of(h, size, magic, pow2);
+        const uint32_t p = slot >> plan.log2_slots;
+        const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+        stage2[pos] = pack_record(slot & slot_mask, g[0] * w, g[1] * w, E, es0);
+      }
+    }
+    __syncthreads();
+    BWDP(4)
+    // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous 8-byte stores
+    uint2* __restrict__ rec = reinterpret_cast<uint2*>(rec_val);
+    for (int p = wave; p < parts; p += kBinThreads / 64) {
+      const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+      const uint64_t dst = (uint64_t)global_base[p];
+      for (uint32_t k = lane; k < cnt; k += 64) rec[dst + k] = stage2[lo + k];
+    }
+  } else {
+    float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
+    if (live) {
+      const Cell<D> c = locate<D>(xi, 0, res);
+#pragma unroll
+      for (int f = 0; f < F; ++f) gmax = fmaxf(gmax, fabsf(g[f]));
+#pragma unroll
+      for (int q = 0; q < G::corners; ++q) {
+        const int nb = sub * G::corners + q;
+        uint32_t h;
+        float w;
+        corner<D>(c, nb, h, w);
+        const uint32_t slot = slot_of(h, size, magic, pow2);
+        const uint32_t p = slot >> plan.log2_slots;
+        const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+        stage[pos] = slot & slot_mask;
+#pragma unroll
+        for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
+    // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
+    // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
+    if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
+    __syncthreads();
+    BWDP(4)
+    if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(max_bits + level, wg_max);
+
+    // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
+    for (int p = wave; p < parts; p += kBinThreads / 64) {
+      const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+      const uint64_t dst = (uint64_t)global_base[p];
+      for (uint32_t k = lane; k < cnt; k += 64) {
+        rec_slot[dst + k] = (uint16_t)stage[lo + k];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
+      }
     }
   }
 #ifdef MRI_BWD_PROFILE
@@ -465,55 +538,93 @@ __device__ __forceinline__ void bin_accumulate_body(
   __syncthreads();
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  // 4 records per lane and load (8- and 16-byte accesses: r_lo, k_lo and `records` are multiples of 4),
-  // kGroups such loads per array in flight before the first LDS atomic: the kernel is latency
-  // bound (78 % of wave cycles in s_waitcnt), not LDS bound
-  constexpr int kGroups = 4;
-  const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
-  const uint16_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
-  const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
-  for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
-    uint2 rel[kGroups];  // four 16-bit slots
-    float4 val[kGroups][F];
+  if constexpr (kPackedRecords<F>) {
+    // packed 8-byte records (pack_record): 4 per lane and pair of 16-byte loads, kGroups pairs in flight;
+    // value = m 2^-(es0 + 4 c), accumulator unit 2^-ex: a shift by ex - es0 - 4 c (44 - log2 n - 4 c)
+    const int sh = ex - rec_exponent(max_bits[level]);  // for class 0; 4 less per class
+    constexpr int kGroups = 4;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const uint2* __restrict__ rec = reinterpret_cast<const uint2*>(rec_val) + (uint64_t)r_lo;
+    const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
+    auto add = [&](uint32_t lo, uint32_t hi) {
+      uint32_t slot;
+      int m0, c0, m1, c1;
+      unpack_record(lo, hi, slot, m0, c0, m1, c1);
+      const int s0 = sh - 4 * c0, s1 = sh - 4 * c1;
+      atomicAdd(&acc[slot * 2], (unsigned long long)(((long long)m0 << max(s0, 0)) >> max(-s0, 0)));
+      atomicAdd(&acc[slot * 2 + 1], (unsigned long long)(((long long)m1 << max(s1, 0)) >> max(-s1, 0)));
+    };
+    for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
+      u4v ra[kGroups], rb[kGroups];
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-      const uint32_t k = k0 + g * 4 * kAccThreads;
-      if (k < k_vec) {
-        // read once: non-temporal loads leave the L2 to the gradient slices written below (25 us)
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        const u2v r_ = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(slot_ptr + k));
-        rel[g] = make_uint2(r_.x, r_.y);
+      for (int g = 0; g < kGroups; ++g) {
+        const uint32_t k = k0 + g * 4 * kAccThreads;
+        if (k < k_vec) {  // read once: non-temporal loads leave the L2 to the gradient slices written below
+          ra[g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k));
+          rb[g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k + 2));
+        }
+      }
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const f4v v_ = __builtin_nontemporal_load(
-              reinterpret_cast<const f4v*>(val_ptr + (uint64_t)f * records + k));
-          val[g][f] = make_float4(v_.x, v_.y, v_.z, v_.w);
+      for (int g = 0; g < kGroups; ++g) {
+        const uint32_t k = k0 + g * 4 * kAccThreads;
+        if (k < k_vec) {
+          add(ra[g].x, ra[g].y), add(ra[g].z, ra[g].w);
+          add(rb[g].x, rb[g].y), add(rb[g].z, rb[g].w);
         }
       }
     }
-#pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-      const uint32_t k = k0 + g * 4 * kAccThreads;
-      if (k < k_vec) {
-        const uint32_t r4[4] = {rel[g].x & 0xffffu, rel[g].x >> 16, rel[g].y & 0xffffu,
-                                rel[g].y >> 16};
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const float v4[4] = {val[g][f].x, val[g][f].y, val[g][f].z, val[g][f].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
+    for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) add(rec[kt].x, rec[kt].y);
+  } else {
+    // 4 records per lane and load (8- and 16-byte accesses: r_lo, k_lo and `records` are multiples of 4),
+    // kGroups such loads per array in flight before the first LDS atomic: the kernel is latency
+    // bound (78 % of wave cycles in s_waitcnt), not LDS bound
+    constexpr int kGroups = 4;
+    const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
+    const uint16_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
+    const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
+    for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
+      uint2 rel[kGroups];  // four 16-bit slots
+      float4 val[kGroups][F];
+  #pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const uint32_t k = k0 + g * 4 * kAccThreads;
+        if (k < k_vec) {
+          // read once: non-temporal loads leave the L2 to the gradient slices written below (25 us)
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const u2v r_ = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(slot_ptr + k));
+          rel[g] = make_uint2(r_.x, r_.y);
+  #pragma unroll
+          for (int f = 0; f < F; ++f) {
+            const f4v v_ = __builtin_nontemporal_load(
+                reinterpret_cast<const f4v*>(val_ptr + (uint64_t)f * records + k));
+            val[g][f] = make_float4(v_.x, v_.y, v_.z, v_.w);
+          }
+        }
+      }
+  #pragma unroll
+      for (int g = 0; g < kGroups; ++g) {
+        const uint32_t k = k0 + g * 4 * kAccThreads;
+        if (k < k_vec) {
+          const uint32_t r4[4] = {rel[g].x & 0xffffu, rel[g].x >> 16, rel[g].y & 0xffffu,
+                                  rel[g].y >> 16};
+  #pragma unroll
+          for (int f = 0; f < F; ++f) {
+            const float v4[4] = {val[g][f].x, val[g][f].y, val[g][f].z, val[g][f].w};
+  #pragma unroll
+            for (int j = 0; j < 4; ++j)
+              atomicAdd(&acc[r4[j] * F + f], (unsigned long long)to_fixed(v4[j], scale_hi));
+          }
         }
       }
     }
-  }
-  for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) {
-    const uint32_t rel_t = slot_ptr[kt];
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      atomicAdd(&acc[rel_t * F + f],
-                (unsigned long long)to_fixed(val_ptr[(uint64_t)f * records + kt], scale_hi));
+    for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) {
+      const uint32_t rel_t = slot_ptr[kt];
+  #pragma unroll
+      for (int f = 0; f < F; ++f)
+        atomicAdd(&acc[rel_t * F + f],
+                  (unsigned long long)to_fixed(val_ptr[(uint64_t)f * records + kt], scale_hi));
+    }
   }
   __syncthreads();
   const int64_t ws_off = plan.ws_offset[e];
@@ -912,8 +1023,18 @@ struct BinnedLaunch {
       uint32_t absmax_levels = 0;  // with the fused launch: dense absmax rides on the scatter grid
       if (fuse_dense)
         for (int e = 0; e < dense.n_entries; ++e) absmax_levels |= 1u << dense.level_of[e];
+      if constexpr (kPackedRecords<F>) {
+        // packed records are scaled by their level's max |g|, which must therefore be complete before the
+        // scatter stages its first record: one pass over d_out for the binned (and fused dense) levels
+        BinPlan both{};
+        for (int e = 0; e < sel.n_entries; ++e) both.level_of[both.n_entries++] = sel.level_of[e];
+        for (int e = 0; fuse_dense && e < dense.n_entries; ++e) both.level_of[both.n_entries++] = dense.level_of[e];
+        hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(64, both.n_entries), dim3(256), 0, st, both, d_out, n,
+                           sl, sr, sf, w.max_bits);
+        absmax_levels = 0;
+      }
       hipLaunchKernelGGL((bin_kernel<D, F, true>),
-                         dim3((unsigned)chunks, sel.n_entries + (fuse_dense ? dense.n_entries : 0)),
+                         dim3((unsigned)chunks, sel.n_entries + (fuse_dense && !kPackedRecords<F> ? dense.n_entries : 0)),
                          dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
                          w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
                          w.records, w.max_bits, absmax_levels);
