@@ -243,6 +243,31 @@ int mri_tiny_mlp_train_slice(const float* x, int64_t x_ld, const float* target, 
                              float* loss_out, float* y, int32_t overwrite, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* mri_tiny_mlp_train[_overwrite] that also reports max |d_x| per PAIR of feature rows: dx_pair_absmax
+ * (k_in / 2 non-negative floats) is raised with atomic maxima, so the caller zeroes it before the call.
+ * With a hash-grid encoder of two features per level this is max |dLoss / d features| per level, the scale
+ * mri_hashgrid_backward_scaled needs for its gradient records -- taken where d_x is produced instead of by
+ * a pass over it.  Served by the bf16-pipe decoder kernel only (mri_tiny_mlp_dx_absmax_supported, else
+ * MRI_ERR_UNSUPPORTED); d_x must be requested. */
+int mri_tiny_mlp_dx_absmax_supported(int32_t k_in, int32_t hidden);
+int mri_tiny_mlp_train_dx_absmax(const float* x, const float* target, int64_t n, int32_t k_in,
+                                 int32_t hidden, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* w3, const float* b3, float grad_divisor,
+                                 float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_w3,
+                                 float* d_b3, float* d_x, float* loss_out, float* y, int32_t overwrite,
+                                 float* dx_pair_absmax, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+
+/* mri_hashgrid_backward_levels with max |d_out| per level supplied by the caller (level_absmax, n_levels
+ * non-negative floats, each >= the true maximum's binade is what matters: values above it would clip;
+ * NULL = found by a pass over d_out, as the other entry points do).  Grids with two features per level
+ * store their gradient records relative to that scale (csrc/hashgrid_bwd.hip, packed records). */
+int mri_hashgrid_backward_scaled(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
+                                 int64_t dout_level_stride, int64_t dout_row_stride,
+                                 int64_t dout_feat_stride, float* d_table, int32_t flags,
+                                 uint32_t level_mask, const float* level_absmax, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+
 /* Encoder + decoder in ONE kernel (reference models.py:739-754, HashMLP.forward = encoder -> ReLU MLP,
  * with F.mse_loss and the decoder's autograd): the decoder's workgroups look the features of their
  * next row tile up themselves while the matrix pipe works on the current one, so the lookup kernel

@@ -66,6 +66,10 @@ SIGNATURES = {
                            _P, _P, _P, _P, _P, _P, _I64, _P],
     "mri_tiny_mlp_train_overwrite": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "mri_tiny_mlp_train_dx_absmax": [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _I32, _P, _P, _I64, _P],
+    "mri_hashgrid_backward_scaled": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _I32,
+                                     C.c_uint32, _P, _P, _I64, _P],
     "mri_hash_tiny_mlp_train": [C.POINTER(GridDesc), _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F,
                                 _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _I32, _P, _I64, _P],
     "mri_hashgrid_backward_input": [C.POINTER(GridDesc), _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
@@ -94,6 +98,7 @@ INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), 
                  "mri_tiny_mlp_round_rows": [_I32, _I32, _I64]}
 INT_GETTERS = {"mri_tiny_mlp_supported": [_I32, _I32, _I32],
                "mri_hash_tiny_mlp_supported": [C.POINTER(GridDesc), _I32],
+               "mri_tiny_mlp_dx_absmax_supported": [_I32, _I32],
                "mri_siren_supported": [_I32, _I32, _I32, _I32]}  # return a plain value, not a status
 
 _lib = None

@@ -691,9 +691,29 @@ __global__ __launch_bounds__(256) void dense_absmax_kernel(const BinPlan plan,
   if (threadIdx.x == 0) wg_max = 0u;
   __syncthreads();
   float m = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  if (sr == 1 && (sf & 3) == 0 && (reinterpret_cast<uintptr_t>(gl) & 15) == 0) {
+    // feature-major block (the fused step's layout): rows of n contiguous values, 16 bytes per load
+    const int64_t n4 = n >> 2;
 #pragma unroll
-    for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(gl[i * sr + f * sf]));
+    for (int f = 0; f < F; ++f) {
+      const float4* __restrict__ row = reinterpret_cast<const float4*>(gl + f * sf);
+      // four loads in flight per thread: one after the other the kernel is a chain of HBM latencies (15 us)
+      const int64_t step = (int64_t)gridDim.x * 256;
+      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * step) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = i + j * step < n4 ? row[i + j * step] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+      }
+      if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(gl[f * sf + 4 * n4 + threadIdx.x]));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(gl[i * sr + f * sf]));
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
@@ -956,7 +976,7 @@ struct BinnedLaunch {
   static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense_all,
                  const Workspace& w, int n_levels, uint32_t level_mask, int phase, int overwrite,
                  const float* x, const float* d_out, int64_t n, int64_t sl, int64_t sr,
-                 int64_t sf, float* d_table, const AdamFuse& ad, hipStream_t st) {
+                 int64_t sf, float* d_table, const AdamFuse& ad, const uint32_t* ext_max, hipStream_t st) {
     // phase 0: everything; 1: count + prefix only (needs x alone, so it can run beside the
     // forward pass); 2: the rest, after a phase-1 call on the same workspace
     if constexpr (D <= 4 && F <= 4) {
@@ -975,13 +995,18 @@ struct BinnedLaunch {
       const BinPlan sel = select_levels(plan, level_mask, acc_blocks);
       // dense levels: their launch is merged with the record accumulation when the call has both
       const bool fuse_dense = dense.n_entries > 0 && sel.n_entries > 0 && options().bwd_fuse_dense;
+      // max |d_out| per level (float bit patterns): the workspace header, filled by a pass over d_out -- or,
+      // packed records only, the caller's array (the decoder kernel that produced d_out knows it already)
+      const bool given = ext_max != nullptr && kPackedRecords<F>;
+      uint32_t* const mx = given ? const_cast<uint32_t*>(ext_max) : w.max_bits;
       if (dense.n_entries > 0 && phase != 1 && !fuse_dense) {
-        hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
-                           dense, d_out, n, sl, sr, sf, w.max_bits);
+        if (!given)
+          hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(128, dense.n_entries), dim3(256), 0, st,
+                             dense, d_out, n, sl, sr, sf, mx);
         if (!fuse_dense)
           hipLaunchKernelGGL((dense_level_kernel<D, F>), dim3((unsigned)dense_blocks),
                              dim3(kAccThreads), 0, st, tab, dense, x, d_out, n, sl, sr, sf,
-                             w.max_bits, w.partial);
+                             mx, w.partial);
       }
       // ONE finalize launch for everything that met in the int64 area: the dense levels and the
       // binned levels whose bins were cut over entry ranges
@@ -998,7 +1023,7 @@ struct BinnedLaunch {
       auto finalize = [&]() {
         if (fin.n_entries > 0)
           hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, fin.n_entries), dim3(256), 0, st, tab,
-                             fin, F, n, d_table, w.max_bits, w.partial, overwrite, ad);
+                             fin, F, n, d_table, mx, w.partial, overwrite, ad);
       };
       if (plan.n_entries == 0) {
         finalize();
@@ -1009,7 +1034,7 @@ struct BinnedLaunch {
       if (phase != 2) {
         hipLaunchKernelGGL((bin_kernel<D, F, false>), bin_grid, dim3(kBinThreads), 0, st, tab, plan,
                            x, d_out, n, sl, sr, sf, w.chunk_hist, w.chunk_base, w.offsets, chunks,
-                           w.rec_slot, w.rec_val, w.records, w.max_bits, 0u);
+                           w.rec_slot, w.rec_val, w.records, mx, 0u);
         hipLaunchKernelGGL(bin_chunk_scan_kernel, dim3((unsigned)plan.total_bins), dim3(64), 0, st,
                            w.chunk_hist, w.chunk_base, w.cursor, chunks);
         hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(256), 0, st, w.cursor, w.offsets,
@@ -1029,25 +1054,26 @@ struct BinnedLaunch {
         BinPlan both{};
         for (int e = 0; e < sel.n_entries; ++e) both.level_of[both.n_entries++] = sel.level_of[e];
         for (int e = 0; fuse_dense && e < dense.n_entries; ++e) both.level_of[both.n_entries++] = dense.level_of[e];
-        hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(64, both.n_entries), dim3(256), 0, st, both, d_out, n,
-                           sl, sr, sf, w.max_bits);
+        if (!given)
+          hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(64, both.n_entries), dim3(256), 0, st, both, d_out,
+                             n, sl, sr, sf, mx);
         absmax_levels = 0;
       }
       hipLaunchKernelGGL((bin_kernel<D, F, true>),
                          dim3((unsigned)chunks, sel.n_entries + (fuse_dense && !kPackedRecords<F> ? dense.n_entries : 0)),
                          dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
                          w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
-                         w.records, w.max_bits, absmax_levels);
+                         w.records, mx, absmax_levels);
       if (fuse_dense)
         hipLaunchKernelGGL((dense_and_accumulate_kernel<D, F>),
                            dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
                            tab, dense, dense_blocks, sel, x, d_out, n, sl, sr, sf, w.offsets,
-                           w.counts, w.rec_slot, w.rec_val, w.records, w.max_bits, d_table,
+                           w.counts, w.rec_slot, w.rec_val, w.records, mx, d_table,
                            w.partial, overwrite, ad);
       else
         hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
                            dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts,
-                           w.rec_slot, w.rec_val, w.records, w.max_bits, d_table, w.partial,
+                           w.rec_slot, w.rec_val, w.records, mx, d_table, w.partial,
                            overwrite, ad);
       finalize();
       return check_launch("hashgrid backward (binned)");
@@ -1077,7 +1103,8 @@ namespace {
 int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out, int64_t n,
                   int64_t sl, int64_t sr, int64_t sf, float* d_table, int32_t method, int phase,
                   int overwrite, uint32_t level_mask, void* workspace,
-                  int64_t workspace_bytes_given, void* stream, const AdamFuse* fuse = nullptr) {
+                  int64_t workspace_bytes_given, void* stream, const AdamFuse* fuse = nullptr,
+                  const float* level_absmax = nullptr) {
   if (int rc = validate(grid)) return rc;
   MRI_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
   MRI_REQUIRE(method >= 0 && method <= 2, "method %d not in 0..2", method);
@@ -1107,7 +1134,8 @@ int backward_impl(const mri_grid_desc* grid, const float* x, const float* d_out,
     const LevelTab tab = make_tab(grid);
     int rc = dispatch<BinnedLaunch>(grid->dim, F, tab, plan, dense, w, grid->n_levels,
                                     level_mask, phase, overwrite, x, d_out, n, sl, sr, sf,
-                                    d_table, ad, (hipStream_t)stream);
+                                    d_table, ad, reinterpret_cast<const uint32_t*>(level_absmax),
+                                    (hipStream_t)stream);
     if (rc) return rc;
   }
   atomic_mask &= level_mask;
@@ -1152,6 +1180,20 @@ extern "C" int mri_hashgrid_backward_levels(const mri_grid_desc* grid, const flo
   return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
                        d_table, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, overwrite,
                        level_mask, workspace, workspace_bytes_given, stream);
+}
+
+extern "C" int mri_hashgrid_backward_scaled(const mri_grid_desc* grid, const float* x,
+                                            const float* d_out, int64_t n,
+                                            int64_t dout_level_stride, int64_t dout_row_stride,
+                                            int64_t dout_feat_stride, float* d_table,
+                                            int32_t method, uint32_t level_mask,
+                                            const float* level_absmax, void* workspace,
+                                            int64_t workspace_bytes_given, void* stream) {
+  const int phase = (method & MRI_BWD_PREPARED) ? 2 : 0;
+  const int overwrite = (method & MRI_BWD_OVERWRITE) ? 1 : 0;
+  return backward_impl(grid, x, d_out, n, dout_level_stride, dout_row_stride, dout_feat_stride,
+                       d_table, method & ~(MRI_BWD_PREPARED | MRI_BWD_OVERWRITE), phase, overwrite,
+                       level_mask, workspace, workspace_bytes_given, stream, nullptr, level_absmax);
 }
 
 extern "C" int mri_hashgrid_backward_adam(const mri_grid_desc* grid, const float* x,

@@ -26,6 +26,9 @@ struct FusedArgs {
   const unsigned long long* ready;
   unsigned long long ready_target;
   int* status;         // set to 1 if a wait gave up (the producer never arrived)
+  // mlp_x3.hip, optional: max |dx| per PAIR of feature rows (k_in / 2 non-negative floats, atomicMax'ed as
+  // their bit patterns: the caller zeroes them) -- the scale the table-gradient records need per level
+  unsigned int* dx_absmax;
 };
 
 

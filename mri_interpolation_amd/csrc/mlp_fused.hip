@@ -1013,7 +1013,7 @@ static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const
                                   float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
                                   float* loss_out, float* y, void* workspace,
                                   int64_t workspace_bytes, void* stream,
-                                  const Overlap& overlap = Overlap()) {
+                                  const Overlap& overlap = Overlap(), float* dx_absmax = nullptr) {
   MRI_REQUIRE(supported(k_in, hidden, 1), "tiny MLP %d -> %d -> %d -> 1 is not supported", k_in,
               hidden, hidden);
   MRI_REQUIRE(n >= 0 && grad_divisor > 0.f, "bad n / grad_divisor");
@@ -1035,6 +1035,10 @@ static int tiny_mlp_train_impl(int overwrite, int64_t ld, int64_t n_total, const
   a.inv_n = (float)(1.0 / (double)n_total);
   a.stagger = std::min(std::max(options().mlp_stagger, 0), 8);
   a.ready = overlap.ready, a.ready_target = overlap.target, a.status = overlap.status;
+  a.dx_absmax = reinterpret_cast<unsigned int*>(dx_absmax);
+  if (dx_absmax && !(use_x3(a, hidden) && d_x))
+    return fail(MRI_ERR_UNSUPPORTED, "max |d_x| per feature pair comes from the bf16-pipe decoder kernel only "
+                                     "(mri_tiny_mlp_dx_absmax_supported), with d_x requested");
   const int blocks = use_x3(a, hidden) ? x3_blocks(n) : pick_blocks(hidden, n);
   const int slabs = blocks;
   if (int rc = dispatch(a, hidden, true, blocks, (hipStream_t)stream)) return rc;
@@ -1143,6 +1147,24 @@ extern "C" int mri_hash_tiny_mlp_train(const mri_grid_desc* grid, const float* t
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(slab, 64)), dim3(256), 0,
                      (hipStream_t)stream, r);
   return check_launch("slab_reduce_kernel");
+}
+
+extern "C" int mri_tiny_mlp_dx_absmax_supported(int32_t k_in, int32_t hidden) {
+  return options().mlp_x3 && x3_supported(k_in, hidden) ? 1 : 0;
+}
+
+extern "C" int mri_tiny_mlp_train_dx_absmax(const float* x, const float* target, int64_t n, int32_t k_in,
+                                            int32_t hidden, const float* w1, const float* b1,
+                                            const float* w2, const float* b2, const float* w3,
+                                            const float* b3, float grad_divisor, float* d_w1, float* d_b1,
+                                            float* d_w2, float* d_b2, float* d_w3, float* d_b3, float* d_x,
+                                            float* loss_out, float* y, int32_t overwrite,
+                                            float* dx_pair_absmax, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
+  MRI_REQUIRE(dx_pair_absmax != nullptr, "NULL dx_pair_absmax");
+  return tiny_mlp_train_impl(overwrite ? 1 : 0, n, n, x, target, n, k_in, hidden, w1, b1, w2, b2, w3, b3,
+                             grad_divisor, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_x, loss_out, y, workspace,
+                             workspace_bytes, stream, Overlap(), dx_pair_absmax);
 }
 
 extern "C" int64_t mri_tiny_mlp_round_rows(int32_t k_in, int32_t hidden, int64_t n) {

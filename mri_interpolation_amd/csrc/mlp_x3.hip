@@ -74,6 +74,7 @@ struct __attribute__((aligned(16))) X3Smem {
   float b1[kX3H], b2[kX3H], w3[kX3H];  // read per tile (registers are the scarce resource here)
   float gc[2][kX3Rows][4];             // gather mode: coordinates of the next two tiles
   float pa[kX3Threads][2];             // gather mode: a thread's partial sums, parked between two segments
+  uint32_t dxmax[16];                  // max |dx| per feature pair (bit patterns), a.dx_absmax
 };
 
 // Three-term fragments at byte offset `off` of an image whose terms are TERM bytes apart.
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     *reinterpret_cast<uint32_t*>(sm.w1[2] + off) = l;
   }
   if (tid < H) sm.b1[tid] = a.b1[tid], sm.b2[tid] = a.b2[tid], sm.w3[tid] = a.w3[tid];
+  if (tid < 16) sm.dxmax[tid] = 0u;
   const float b3 = a.b3[0];
 
   f32x4 g_w2[U][KT], g_w1[U][2];
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         return f;
       };
       wa[0] = w1t_frag(0), zc[0] = ld_row<IMG>(i_z1, a_row + 4096 * bt);
+      const uint32_t seen0 = sm.dxmax[8 * kt + 2 * g], seen1 = sm.dxmax[8 * kt + 2 * g + 1];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         if (s + 1 < KS) {
@@ -698,10 +701,23 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         const int k = 16 * kt + 4 * g + r;
         if (k < a.k_in && live) dxs[(uint32_t)k * ld32 + 16 * bt + li] = c[r];
       }
+      if (TRAIN && a.dx_absmax) {
+        // max |dx| per feature pair (rows beyond n have dz = 0, hence c = 0), kept in LDS: two more
+        // registers across the tile loop cost this kernel 9 %
+        const float d0 = fmaxf(fabsf(c[0]), fabsf(c[1])), d1 = fmaxf(fabsf(c[2]), fabsf(c[3]));
+        // (the running maxima were read before the MFMAs: after a few tiles no lane raises them any more,
+        // and a stale value only costs an atomic that changes nothing)
+        if (__float_as_uint(d0) > seen0) atomicMax(&sm.dxmax[8 * kt + 2 * g], __float_as_uint(d0));
+        if (__float_as_uint(d1) > seen1) atomicMax(&sm.dxmax[8 * kt + 2 * g + 1], __float_as_uint(d1));
+      }
     }
     if (has_next) layer1(buf ^ 1);
   }
 #undef X3_PIN
+  if (TRAIN && a.dx && a.dx_absmax) {
+    __syncthreads();
+    if (tid < 16 && 2 * tid < a.k_in) atomicMax(a.dx_absmax + tid, sm.dxmax[tid]);
+  }
   X3P_MARK(18)
   if (!TRAIN) {
     X3P_END

@@ -139,10 +139,12 @@ def hashgrid_backward_prepare(desc: GridDesc, x: torch.Tensor, method: int = 0, 
 def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
                       d_table: torch.Tensor, feature_major: bool = False, method: int = 0,
                       prepared: bool = False, overwrite: bool = False,
-                      level_mask: Optional[int] = None, ws: Optional[torch.Tensor] = None):
+                      level_mask: Optional[int] = None, ws: Optional[torch.Tensor] = None,
+                      level_absmax: Optional[torch.Tensor] = None):
     """d_table += scatter of d_out (or d_table = ..., with overwrite=True); `level_mask`
     restricts the call to the levels whose bit is set (one level group of a bucketed,
-    data-parallel backward)."""
+    data-parallel backward); `level_absmax` (n_levels floats on the device): max |d_out| per level
+    when the caller has it already (tiny_mlp_train(..., dx_absmax=)), saving a pass over d_out."""
     _gpu(x, d_out, d_table)
     x = _rowmajor(x).contiguous()
     n = x.shape[0]
@@ -155,7 +157,14 @@ def hashgrid_backward(desc: GridDesc, x: torch.Tensor, d_out: torch.Tensor,
         ws = backward_workspace(desc, n, x.device)
     flags = (method | (_lib.BWD_PREPARED if prepared else 0)
              | (_lib.BWD_OVERWRITE if overwrite else 0))
-    if level_mask is None:
+    if level_absmax is not None:
+        _gpu(level_absmax)
+        if level_absmax.numel() < desc.n_levels or level_absmax.dtype != torch.float32:
+            raise ValueError("level_absmax: one float32 per level")
+        _lib.call("mri_hashgrid_backward_scaled", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr,
+                  sf, _ptr(d_table), flags, (0xFFFFFFFF if level_mask is None else level_mask) & 0xFFFFFFFF,
+                  _ptr(level_absmax), _ptr(ws), ws.numel() * 8 if ws is not None else 0, _stream())
+    elif level_mask is None:
         _lib.call("mri_hashgrid_backward", C.byref(desc), _ptr(x), _ptr(d_out), n, sl, sr, sf,
                   _ptr(d_table), flags, _ptr(ws), ws.numel() * 8 if ws is not None else 0,
                   _stream())
@@ -442,15 +451,31 @@ def tiny_mlp_forward(x_fm, params, y=None):
     return y
 
 
+def tiny_mlp_dx_absmax_supported(k_in: int, hidden: int) -> bool:
+    """Can tiny_mlp_train report max |d_x| per pair of feature rows (dx_absmax=)?"""
+    return bool(_lib.load().mri_tiny_mlp_dx_absmax_supported(int(k_in), int(hidden)))
+
+
 def tiny_mlp_train(x_fm, target, params, grads, loss_out, d_x=None, y=None,
-                   grad_divisor: float = 1.0, overwrite: bool = False):
+                   grad_divisor: float = 1.0, overwrite: bool = False, dx_absmax=None):
     """Forward + MSE + backward of the tiny MLP in one kernel; grads accumulate (or are
-    overwritten, together with loss_out, when overwrite=True)."""
+    overwritten, together with loss_out, when overwrite=True).  `dx_absmax` (k_in / 2 zeroed floats
+    on the device) receives max |d_x| per pair of feature rows (hashgrid_backward's level_absmax)."""
     (w1, b1), (w2, b2), (w3, b3) = params
     (g1, gb1), (g2, gb2), (g3, gb3) = grads
     _gpu(x_fm, target, w1, b1, w2, b2, w3, b3, g1, gb1, g2, gb2, g3, gb3, loss_out, d_x, y)
     k_in, n = x_fm.shape
     ws = _tiny_workspace(k_in, w1.shape[0], n, x_fm.device)
+    if dx_absmax is not None:
+        _gpu(dx_absmax)
+        if dx_absmax.numel() < (k_in + 1) // 2 or dx_absmax.dtype != torch.float32:
+            raise ValueError("dx_absmax: one float32 per pair of feature rows")
+        _lib.call("mri_tiny_mlp_train_dx_absmax", _ptr(x_fm), _ptr(target), n, k_in, w1.shape[0],
+                  _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor),
+                  _ptr(g1), _ptr(gb1), _ptr(g2), _ptr(gb2), _ptr(g3), _ptr(gb3), _ptr(d_x),
+                  _ptr(loss_out), _ptr(y), 1 if overwrite else 0, _ptr(dx_absmax), _ptr(ws),
+                  ws.numel() * 4, _stream())
+        return loss_out
     _lib.call("mri_tiny_mlp_train_overwrite" if overwrite else "mri_tiny_mlp_train", _ptr(x_fm),
               _ptr(target), n, k_in, w1.shape[0], _ptr(w1),
               _ptr(b1), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), float(grad_divisor), _ptr(g1),

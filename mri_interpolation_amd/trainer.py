@@ -125,6 +125,13 @@ class FusedStep:
         # (config 4: 0.572 -> 0.561 ms).  The 64-wide kernel leaves room, there the extra work beside
         # the lookup only costs (config 2: 0.449 -> 0.458 ms).
         self.count_ahead = self.use_tiny and self.layers[0].weight.shape[0] == 128
+        # the decoder kernel reports max |d_enc| per level, the scale of the table-gradient records
+        # (two features per level: feature pair = level)
+        self.decoder_absmax = bool(
+            self.use_tiny and self.encoder is not None and self.encoder.n_features_per_level == 2
+            and ops.tiny_mlp_dx_absmax_supported(self.layers[0].weight.shape[1],
+                                                 self.layers[0].weight.shape[0]))
+        self._absmax, self._absmax_index, self._absmax_clean = None, 0, [True, True]
         # Fused decoder, optional: cut the batch in two slices and run the encoder of the second
         # on its own stream beside the decoder kernel of the first (the decoder leaves the VALU
         # and the texture path idle, the encoder needs no LDS).  Measured at BASELINE config 4:
@@ -347,7 +354,22 @@ class FusedStep:
         self._bucket_cache = (self.grad_buckets, out)
         return out
 
-    def _hash_backward(self, coords, d_enc, overwrite=False, reduce=True):
+    def _take_absmax(self):
+        """A zeroed buffer for the decoder's max |d_enc| per level, or None if this decoder / encoder
+        pair does not use one.  Two buffers alternate: the one for the NEXT step is zeroed on the side
+        stream beside this step (train_step: queue_side), otherwise here, on the main stream."""
+        if not self.decoder_absmax:
+            return None
+        if self._absmax is None:
+            self._absmax = torch.zeros(2, 32, device=self.flat.param.device)
+            self._absmax_clean = [True, True]
+        i = self._absmax_index = 1 - self._absmax_index
+        if not self._absmax_clean[i]:
+            self._absmax[i].zero_()
+        self._absmax_clean[i] = False
+        return self._absmax[i]
+
+    def _hash_backward(self, coords, d_enc, overwrite=False, reduce=True, absmax=None):
         """Table gradient; with several ranks, reduce each finished level group right away
         (`reduce=False`: a micro-batch of an accumulation group that does not step)."""
         enc = self.encoder
@@ -358,7 +380,7 @@ class FusedStep:
         if self.grad_buckets <= 1 or not reduce or self.dp_mode == "reduce_scatter":
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
                                   method=self.bwd_method, prepared=counted, overwrite=overwrite,
-                                  ws=ws)
+                                  ws=ws, level_absmax=absmax)
             return []
         if not counted and self.bwd_method != 1:  # one count for all the groups
             ops.hashgrid_backward_prepare(enc.desc, coords, self.bwd_method, ws=ws)
@@ -367,7 +389,7 @@ class FusedStep:
         for mask, grad_slice in self._level_buckets():
             ops.hashgrid_backward(enc.desc, coords, d_enc, self._table_grad, feature_major=True,
                                   method=self.bwd_method, prepared=counted, overwrite=overwrite,
-                                  level_mask=mask, ws=ws)
+                                  level_mask=mask, ws=ws, level_absmax=absmax)
             pending.append(self._reduce_async(grad_slice))
         return pending
 
@@ -444,6 +466,7 @@ class FusedStep:
                 h, n = self._split_rows, coords.shape[0]
                 if not first:
                     self.loss.zero_()  # the kernels add to it: keep it this batch's loss
+                absmax = None
                 if self._overlapped:
                     ops.tiny_mlp_train_overlapped(ws["enc"], target, self.tiny["params"],
                                                   self.tiny["grads"], self.loss, ws["d_enc"],
@@ -465,16 +488,20 @@ class FusedStep:
                                              self.tiny["grads"], self.loss, ws["d_enc"],
                                              grad_divisor=div, overwrite=False)
                 else:
+                    # a whole batch in one decoder call: the kernel reports max |d_enc| per level
+                    # on the way (the scale of the table-gradient records), no pass over d_enc
+                    absmax = self._take_absmax() if (first and step) else None
                     ops.tiny_mlp_train(ws["enc"], target, self.tiny["params"],
                                        self.tiny["grads"], self.loss, d_x=ws["d_enc"],
-                                       grad_divisor=div, overwrite=first)
+                                       grad_divisor=div, overwrite=first, dx_absmax=absmax)
             started = self._reduce_decoder_grads() if step else []
             with self._phase("hashgrid_bwd"):
                 if first and step and self._hash_backward_adam(coords, ws["d_enc"]):
                     self._pending = []
                 else:
                     self._pending = started + self._hash_backward(coords, ws["d_enc"],
-                                                                  overwrite=first, reduce=step)
+                                                                  overwrite=first, reduce=step,
+                                                                  absmax=absmax)
             return
         with self._phase("zero_grad"):
             if first:
@@ -568,6 +595,12 @@ class FusedStep:
                 def queue_side():
                     with torch.cuda.stream(self._side):
                         nxt = work()
+                        if self._absmax is not None:
+                            # the buffer of the step BEFORE this one (free since the wait_stream above)
+                            # is the next step's: zero it here, behind _batch_event (see _take_absmax)
+                            j = self._absmax_index
+                            self._absmax[j].zero_()
+                            self._absmax_clean[j] = True
                     # the next step's forward pass reads what side_work produced: it waits for this
                     # event (the wait for the counting stage no longer covers it once that runs ahead)
                     self._batch_event = torch.cuda.Event()

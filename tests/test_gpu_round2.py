@@ -885,3 +885,66 @@ def test_one_kernel_encoder_decoder_equals_the_two_kernel_step(amd, dim, levels,
         for ga, gb in zip(wa, wb):
             assert torch.equal(ga, gb)
 
+
+
+# ------------------------------------------- max |d_enc| per level straight from the decoder kernel
+@pytest.mark.parametrize("hidden,levels,n", [(128, 16, 1 << 18), (64, 16, 70001), (128, 5, 33), (64, 8, 4097)])
+def test_decoder_reports_the_level_maxima_of_its_input_gradient(amd, hidden, levels, n):
+    """mri_tiny_mlp_train_dx_absmax: max |d_x| per pair of feature rows, exactly (a maximum has no rounding),
+    and the table gradient computed with them (mri_hashgrid_backward_scaled) equals, bit for bit, the one
+    whose scale comes from the pass over d_x."""
+    from mri_interpolation_amd import ops
+    torch.manual_seed(hidden + levels + n)
+    k_in = 2 * levels
+    assert ops.tiny_mlp_dx_absmax_supported(k_in, hidden)
+    enc = amd.encoding.MultiResHashGrid(3, levels, 2, 17, 16, 512).cuda()
+    x = torch.rand(n, 3, device="cuda")
+    feats = torch.randn(k_in, n, device="cuda") * 0.1
+    t = torch.rand(n, device="cuda")
+    mk = lambda *s_: torch.randn(*s_, device="cuda")  # noqa: E731
+    params = [(mk(hidden, k_in) / k_in ** 0.5, mk(hidden) * 0.1), (mk(hidden, hidden) / hidden ** 0.5, mk(hidden) * 0.1),
+              (mk(1, hidden) / hidden ** 0.5, mk(1) * 0.1)]
+    grads = [tuple(torch.zeros_like(p) for p in wb) for wb in params]
+    loss = torch.zeros(1, device="cuda")
+    d = torch.empty(k_in, n, device="cuda")
+    am = torch.zeros(32, device="cuda")
+    ops.tiny_mlp_train(feats, t, params, grads, loss, d_x=d, overwrite=True, dx_absmax=am)
+    want = d.abs().reshape(levels, 2, n).amax(dim=(1, 2))
+    assert torch.equal(am[:levels], want) and float(am[levels:].abs().max()) == 0.0
+    ga, gb = torch.zeros_like(enc.table.data), torch.zeros_like(enc.table.data)
+    ops.hashgrid_backward(enc.desc, x, d, ga, feature_major=True, overwrite=True)
+    ops.hashgrid_backward(enc.desc, x, d, gb, feature_major=True, overwrite=True, level_absmax=am)
+    assert torch.equal(ga, gb)
+    half = 0xAAAA & ((1 << levels) - 1)  # a level group, as the data-parallel step uses them
+    gc = torch.zeros_like(enc.table.data)
+    ops.hashgrid_backward(enc.desc, x, d, gc, feature_major=True, overwrite=True, level_absmax=am, level_mask=half)
+    ops.hashgrid_backward(enc.desc, x, d, gc, feature_major=True, overwrite=True, level_absmax=am,
+                          level_mask=~half & ((1 << levels) - 1))
+    assert torch.equal(ga, gc)
+
+
+def test_fused_step_with_decoder_maxima_equals_the_step_with_the_pass(amd):
+    """FusedStep.decoder_absmax (default where the bf16-pipe decoder serves the step): parameters after several
+    steps, with and without side work, equal those of the step that scans d_enc -- bit for bit."""
+    vol = amd.datamodules.phantom_volume((40, 37, 29)).cpu().numpy()
+    runs = []
+    for use in (True, False):
+        torch.manual_seed(5)
+        net = amd.models.HashMLP(3, 8, 2, 14, 8, 64, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
+                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
+        step = amd.trainer.FusedStep(net, net.configure_optimizers())
+        assert step.decoder_absmax
+        step.decoder_absmax = use
+        ds = amd.datamodules.MriImage(volume=vol)
+        pipe = amd.datamodules.BatchPipeline(amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, seed=3))
+        for k in range(25):
+            x, y = pipe.current()
+            if k % 7 == 3:  # a step without side work: the buffer is zeroed on the main stream
+                pipe.produce_next()
+                step.train_step(x, y)
+            else:
+                step.train_step(x, y, pipe.produce_next)
+            pipe.advance()
+        torch.cuda.synchronize()
+        runs.append(step.flat.param.clone())
+    assert torch.equal(runs[0], runs[1])
