@@ -360,6 +360,9 @@ class FusedStep:
         stream beside this step (train_step: queue_side), otherwise here, on the main stream."""
         if not self.decoder_absmax:
             return None
+        w1 = self.layers[0].weight  # (the library option that selects the decoder kernel may have changed)
+        if not ops.tiny_mlp_dx_absmax_supported(w1.shape[1], w1.shape[0]):
+            return None
         if self._absmax is None:
             self._absmax = torch.zeros(2, 32, device=self.flat.param.device)
             self._absmax_clean = [True, True]
