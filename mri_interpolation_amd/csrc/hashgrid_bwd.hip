@@ -46,8 +46,13 @@ __device__ long long* g_bwd_profile = nullptr;
     g_bwd_profile[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (k) == 0 || (k) == 7 \
                                                                                  ? wall_clock64() \
                                                                                  : clock64();
+// (accumulate workgroups: slots of their own behind the scatter's)
+#define BWDA(k)                                                                                  \
+  if (g_bwd_profile && threadIdx.x == 0)                                                         \
+    g_bwd_profile[(65536 + (int64_t)blockIdx.x) * 8 + (k)] = (k) == 0 || (k) == 7 ? wall_clock64() : clock64();
 #else
 #define BWDP(k)
+#define BWDA(k)
 #endif
 
 #ifndef MRI_ACC_WORDS  // A/B builds: accumulators (and threads) of an accumulate workgroup
@@ -517,6 +522,7 @@ __device__ __forceinline__ void bin_accumulate_body(
     return;
   }
 
+  BWDA(0) BWDA(1)
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
   // fused Adam: this slice's parameters and moments are fetched NOW, before the record phase (read at
   // the end they would add their full HBM latency to every workgroup: 0.21 -> 0.28 ms measured)
@@ -536,6 +542,7 @@ __device__ __forceinline__ void bin_accumulate_body(
     }
   }
   __syncthreads();
+  BWDA(2)
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
   if constexpr (kPackedRecords<F>) {
@@ -626,7 +633,9 @@ __device__ __forceinline__ void bin_accumulate_body(
                   (unsigned long long)to_fixed(val_ptr[(uint64_t)f * records + kt], scale_hi));
     }
   }
+  BWDA(3)
   __syncthreads();
+  BWDA(4)
   const int64_t ws_off = plan.ws_offset[e];
   if (ws_off < 0) {  // sole owner of the slice: convert once, add to the f32 gradient
     const double inv_scale = __builtin_ldexp(1.0, -ex);
@@ -659,6 +668,11 @@ __device__ __forceinline__ void bin_accumulate_body(
     for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
       if (acc[s]) atomicAdd(dst + s, acc[s]);
   }
+#ifdef MRI_BWD_PROFILE
+  BWDA(5)
+  __builtin_amdgcn_s_waitcnt(0);
+  BWDA(6) BWDA(7)
+#endif
 }
 
 template <int F>
