@@ -523,6 +523,25 @@ __device__ __forceinline__ void bin_accumulate_body(
   }
 
   BWDA(0) BWDA(1)
+  // packed records: two sets of kGroups x 4 records per lane, the next set's loads in flight while this
+  // one's values go into LDS -- and the first set requested BEFORE the slice is zeroed: with one
+  // workgroup per CU every latency a workgroup waits out is idle CU time (tools/bwd_segments.py)
+  constexpr int kPG = 2;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const uint2* __restrict__ rec = reinterpret_cast<const uint2*>(rec_val) + (uint64_t)r_lo;
+  const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u), k_step = 4 * kAccThreads * kPG;
+  u4v ra[2][kPG], rb[2][kPG];
+  auto load_set = [&](int set, uint32_t k0) {
+#pragma unroll
+    for (int g = 0; g < kPG; ++g) {
+      const uint32_t k = k0 + g * 4 * kAccThreads;
+      if (k < k_vec) {  // read once: non-temporal loads leave the L2 to the gradient slices written below
+        ra[set][g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k));
+        rb[set][g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k + 2));
+      }
+    }
+  };
+  if constexpr (kPackedRecords<F>) load_set(0, k_lo + 4 * threadIdx.x);
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
   // fused Adam: this slice's parameters and moments are fetched NOW, before the record phase (read at
   // the end they would add their full HBM latency to every workgroup: 0.21 -> 0.28 ms measured)
@@ -546,13 +565,9 @@ __device__ __forceinline__ void bin_accumulate_body(
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
   if constexpr (kPackedRecords<F>) {
-    // packed 8-byte records (pack_record): 4 per lane and pair of 16-byte loads, kGroups pairs in flight;
-    // value = m 2^-(es0 + 4 c), accumulator unit 2^-ex: a shift by ex - es0 - 4 c (44 - log2 n - 4 c)
+    // packed 8-byte records (pack_record): value = m 2^-(es0 + 4 c), accumulator unit 2^-ex: a shift by
+    // ex - es0 - 4 c (44 - log2 n - 4 c)
     const int sh = ex - rec_exponent(max_bits[level]);  // for class 0; 4 less per class
-    constexpr int kGroups = 4;
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const uint2* __restrict__ rec = reinterpret_cast<const uint2*>(rec_val) + (uint64_t)r_lo;
-    const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
     auto add = [&](uint32_t lo, uint32_t hi) {
       uint32_t slot;
       int m0, c0, m1, c1;
@@ -561,24 +576,21 @@ __device__ __forceinline__ void bin_accumulate_body(
       atomicAdd(&acc[slot * 2], (unsigned long long)(((long long)m0 << max(s0, 0)) >> max(-s0, 0)));
       atomicAdd(&acc[slot * 2 + 1], (unsigned long long)(((long long)m1 << max(s1, 0)) >> max(-s1, 0)));
     };
-    for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
-      u4v ra[kGroups], rb[kGroups];
+    auto add_set = [&](int set, uint32_t k0) {
 #pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        const uint32_t k = k0 + g * 4 * kAccThreads;
-        if (k < k_vec) {  // read once: non-temporal loads leave the L2 to the gradient slices written below
-          ra[g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k));
-          rb[g] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(rec + k + 2));
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
+      for (int g = 0; g < kPG; ++g) {
         const uint32_t k = k0 + g * 4 * kAccThreads;
         if (k < k_vec) {
-          add(ra[g].x, ra[g].y), add(ra[g].z, ra[g].w);
-          add(rb[g].x, rb[g].y), add(rb[g].z, rb[g].w);
+          add(ra[set][g].x, ra[set][g].y), add(ra[set][g].z, ra[set][g].w);
+          add(rb[set][g].x, rb[set][g].y), add(rb[set][g].z, rb[set][g].w);
         }
       }
+    };
+    for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 2 * k_step) {  // (set 0 of the first round is loaded)
+      load_set(1, k0 + k_step);
+      add_set(0, k0);
+      load_set(0, k0 + 2 * k_step);
+      add_set(1, k0 + k_step);
     }
     for (uint32_t kt = k_vec + threadIdx.x; kt < k_hi; kt += kAccThreads) add(rec[kt].x, rec[kt].y);
   } else {
