@@ -281,6 +281,8 @@ def main():
                     help="run the hash-grid lookup beside the decoder kernel (FusedStep.overlap_forward)")
     ap.add_argument("--no-count-ahead", action="store_true",
                     help="count the table-gradient records inside their own step (FusedStep.count_ahead = False)")
+    ap.add_argument("--count-ahead", action="store_true",
+                    help="count them one step ahead whatever the decoder (default: the 128-wide decoder only)")
     ap.add_argument("--fused-adam", action="store_true",
                     help="apply the table's Adam step where its gradient is complete "
                          "(FusedStep.fuse_table_adam; measured -2 %% on cfg4, +2 %% on cfg2 / cfg5: off)")
@@ -328,6 +330,8 @@ def main():
     step.fuse_table_adam = args.fused_adam
     if args.no_count_ahead:
         step.count_ahead = False
+    if args.count_ahead:
+        step.count_ahead = True
     if args.grad_buckets:
         step.grad_buckets = args.grad_buckets
     if args.split is not None:
