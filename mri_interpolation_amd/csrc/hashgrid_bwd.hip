@@ -50,9 +50,14 @@ __device__ long long* g_bwd_profile = nullptr;
 #define BWDA(k)                                                                                  \
   if (g_bwd_profile && threadIdx.x == 0)                                                         \
     g_bwd_profile[(65536 + (int64_t)blockIdx.x) * 8 + (k)] = (k) == 0 || (k) == 7 ? wall_clock64() : clock64();
+// (dense workgroups: behind the accumulate ones)
+#define BWDD(k)                                                                                  \
+  if (g_bwd_profile && threadIdx.x == 0)                                                         \
+    g_bwd_profile[(65536 + 4096 + (int64_t)b) * 8 + (k)] = (k) == 0 || (k) == 7 ? wall_clock64() : clock64();
 #else
 #define BWDP(k)
 #define BWDA(k)
+#define BWDD(k)
 #endif
 
 #ifndef MRI_ACC_WORDS  // A/B builds: accumulators (and threads) of an accumulate workgroup
@@ -769,8 +774,10 @@ __device__ __forceinline__ void dense_level_body(
   const int64_t per = (n + splits - 1) / splits;
   const int64_t i_begin = (int64_t)split * per, i_end = min(n, i_begin + per);
 
+  BWDD(0) BWDD(1)
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
   __syncthreads();
+  BWDD(2)
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
   const float* __restrict__ res = tab.res[level];
@@ -793,10 +800,17 @@ __device__ __forceinline__ void dense_level_body(
       }
     }
   }
+  BWDD(3)
   __syncthreads();
+  BWDD(4)
   unsigned long long* __restrict__ dst = partial + plan.ws_offset[e] + (uint64_t)base * F;
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads)
     if (acc[s]) atomicAdd(dst + s, acc[s]);
+#ifdef MRI_BWD_PROFILE
+  BWDD(5)
+  __builtin_amdgcn_s_waitcnt(0);
+  BWDD(6) BWDD(7)
+#endif
 }
 
 template <int D, int F>

@@ -35,7 +35,7 @@ def main():
     g = torch.zeros_like(enc.table.data)
     lib = _lib.load()
     chunks, rows = n // 512, 16
-    prof = torch.zeros((65536 + 4096) * 8, dtype=torch.int64, device="cuda")
+    prof = torch.zeros((65536 + 8192) * 8, dtype=torch.int64, device="cuda")
     run = lambda: ops.hashgrid_backward(enc.desc, x, d, g, feature_major=True, method=2, overwrite=True)
     for _ in range(3):
         run()
@@ -66,7 +66,7 @@ def main():
     print("  first start per grid row (us):", " ".join(f"{(float(p[r, :, 0][live[r]].min()) - t0) * 0.01:.0f}" if live[r].any() else "-" for r in range(rows)))
     cyc = float((q[:, 6] - q[:, 1]).mean())
     print(f"  {cyc:.0f} shader cycles per lifetime -> {cyc / (float(life.mean()) * 1e-3):.0f} MHz")
-    a = full[65536 * 8:].reshape(-1, 8)
+    a = full[65536 * 8:(65536 + 4096) * 8].reshape(-1, 8)
     a = a[a[:, 7] > 0].double()
     print(f"{a.shape[0]} accumulate workgroups stamped (the dense ones of the merged launch are not)")
     for i, nm in enumerate(["zero the slice (barrier)", "records: loads + LDS atomics", "last wave (barrier)",
@@ -77,6 +77,15 @@ def main():
     sp = float(a[:, 7].max() - a[:, 0].min()) * 10.0
     print(f"  lifetime {float(la.mean()) / 1e3:.2f} us mean (max {float(la.max()) / 1e3:.1f}), span {sp / 1e3:.1f} us, "
           f"in flight {float(la.sum()) / sp / 256:.2f} per CU")
+    dd = full[(65536 + 4096) * 8:].reshape(-1, 8)
+    dd = dd[dd[:, 7] > 0].double()
+    print(f"{dd.shape[0]} dense workgroups stamped")
+    for i, nm in enumerate(["zero the slice (barrier)", "corners of the range: hash, LDS atomics", "last wave (barrier)",
+                            "merge into the int64 area (global atomics) issued", "atomics acknowledged"]):
+        d = dd[:, i + 2] - dd[:, i + 1]
+        print(f"  {nm:52s} {float(d.mean()):9.0f} cycles  (median {float(d.median()):.0f})")
+    ld = (dd[:, 7] - dd[:, 0]) * 10.0
+    print(f"  lifetime {float(ld.mean()) / 1e3:.2f} us mean (max {float(ld.max()) / 1e3:.1f})")
 
 
 if __name__ == "__main__":
