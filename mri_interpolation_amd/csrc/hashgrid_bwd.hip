@@ -782,11 +782,31 @@ __device__ __forceinline__ void dense_level_body(
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
   const float* __restrict__ res = tab.res[level];
   const float* __restrict__ gl = d_out + (int64_t)level * sl;
-  for (int64_t i = i_begin + threadIdx.x; i < i_end; i += kAccThreads) {
-    const Cell<D> c = locate<D>(x, i, res);
-    float g[F];
+  // A thread walks ~20 coordinates; the next one's coordinate and gradient are requested before this one's
+  // corners are hashed: loaded at the top of each iteration the walk was a chain of 20 global round trips
+  // (tools/bwd_segments.py: 46 us per workgroup, vector ALU a good half busy)
+  float xn[D], gn[F];
+  int64_t i = i_begin + threadIdx.x;
+  if (i < i_end) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) g[f] = gl[i * sr + f * sf];
+    for (int d = 0; d < D; ++d) xn[d] = x[i * D + d];
+#pragma unroll
+    for (int f = 0; f < F; ++f) gn[f] = gl[i * sr + f * sf];
+  }
+  for (; i < i_end; i += kAccThreads) {
+    float xi[D], g[F];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xi[d] = xn[d];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = gn[f];
+    const int64_t j = i + kAccThreads;
+    if (j < i_end) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xn[d] = x[j * D + d];
+#pragma unroll
+      for (int f = 0; f < F; ++f) gn[f] = gl[j * sr + f * sf];
+    }
+    const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
     for (int nb = 0; nb < (1 << D); ++nb) {
       uint32_t h;
