@@ -25,10 +25,12 @@
 //   6. finalize   bins that were cut into several entry ranges meet in an int64 workspace.
 // Coarse levels (few slices) skip 2-5: dense_level_kernel evaluates every corner per slice instead.
 // Integer addition is associative: the table gradient is BITWISE REPRODUCIBLE (independent of
-// scheduling and of the order the records landed in), and more accurate than an f32 running sum
-// (>= 40 fraction bits below max|g|; |sum| <= n * max|g| < 2^61 cannot overflow).
-// Algorithmic traffic: records are 2 + 4 F bytes (16-bit slot within the slice + F values),
-// written once and read once.
+// scheduling and of the order the records landed in); the sums keep >= 40 fraction bits below
+// max|g| (|sum| <= n * max|g| < 2^61 cannot overflow).
+// Records, written once and read once: F = 2 (the grids of this project): ONE 8-byte word, 13-bit slot
+// within the slice + two values of 3-bit class and 22-bit mantissa relative to the level's max|g|
+// (pack_record below: each value rounded to 18-21 significant bits before the exact sum); other F:
+// 2 + 4 F bytes (16-bit slot + F float values).
 #include <algorithm>
 #include <cmath>
 
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
 // A level whose table is cut into only a few slices does not need records at all: a workgroup
 // (level, slice, coordinate range) can afford to evaluate the corners of every coordinate of its
 // range and add the ones that fall into its slice straight into LDS -- the redundancy is the
-// number of slices (<= bwd_dense_max_parts), against 20 bytes of record traffic per corner.
+// number of slices (<= bwd_dense_max_parts), against a record written and read per corner.
 // Ranges meet in the int64 workspace like the entry ranges of the binned levels.
 template <int F>
 __global__ __launch_bounds__(256) void dense_absmax_kernel(const BinPlan plan,
