@@ -37,7 +37,20 @@ MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6
 ARITHMETIC = ("f32 values and f32 accumulation everywhere; matrix products as six bf16 MFMAs per product on "
               "operands split EXACTLY into three bf16 terms (per-product error below f32 rounding, measured "
               "equal to v_mfma_f32_32x32x2_f32: DESIGN.md 4.9, tests/test_bf16x3_cpu.py); hash / gather / "
-              "scatter / Adam in plain f32 and 64-bit fixed point")
+              "Adam in plain f32; table gradient: ")
+# the table-gradient records (mri_set_option("bwd_records")): what is added up, said in the line
+RECORDS = {
+    "f32": (0, "every contribution w*g is the f32 product the reference's autograd forms "
+               "(encoding.py:127-128), the sum over a slot is EXACT (64-bit fixed point, bitwise reproducible) "
+               "and rounded once to f32"),
+    "packed": (1, "each contribution w*g rounded to 18-21 significant bits (8-byte packed records) before an "
+                  "exact integer sum: NOT f32-equivalent, 4-64x the rounding of an f32 product per contribution "
+                  "(tests/test_gpu_round3.py::test_record_formats_per_slot_against_float64)"),
+}
+
+
+def arithmetic(records):
+    return ARITHMETIC + RECORDS[records][1]
 
 
 def mfma_roof(step, achieved_tf):
@@ -126,7 +139,7 @@ def phase_model(w, step, n_params):
     return out
 
 
-def pmc_traffic(workload, phase):
+def pmc_traffic(workload, phase, records="f32"):
     """HBM bytes per launch of the phase's kernels from the committed rocprofv3 PMC summary
     (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections applied as the summary
     states) -- measured offline by tools/summarize_prof.py, None when no summary is committed."""
@@ -135,7 +148,10 @@ def pmc_traffic(workload, phase):
         return None
     with open(path) as f:
         table = json.load(f)
-    return table.get(workload, {}).get(phase)
+    entry = table.get(workload, {})
+    if records != "f32":  # summaries of the other record format are filed under "<workload>_<records>"
+        entry = table.get(f"{workload}_{records}", {})
+    return entry.get(phase)
 
 
 def cpu_baseline(w, name):
@@ -238,7 +254,7 @@ def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
     result = {"metric": "coord-samples/sec (predict)", "value": value, "unit": "coord-samples/s",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arithmetic": arithmetic(args.records),
               "data": data_name,
               "config": {"workload": f"{args.workload} predict: dense grid "
                                      f"{'x'.join(map(str, full.shape))}, {w['model']}, "
@@ -289,8 +305,19 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "predict"],
                     help="predict: inference throughput of the same model on the dense grid of "
                          "the volume (launcher.py's predict / interpolate passes), no training")
-    ap.add_argument("--dp-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
-                    help="gradient exchange of the data-parallel step (FusedStep.dp_mode)")
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "all_reduce", "reduce_scatter"],
+                    help="gradient exchange of the data-parallel step (FusedStep.dp_mode); auto (several "
+                         "GPUs): plain all-reduce, bucketed all-reduce and reduce-scatter legs back to back, "
+                         "`value` = the fastest leg whose replicas stayed identical")
+    ap.add_argument("--leg-timeout", type=float, default=240.0,
+                    help="seconds the legs after the first may take before the line of the finished legs is printed")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="rehearsal: accept a gloo process group for --gpus > 1 (never a measured line)")
+    ap.add_argument("--records", default="f32", choices=sorted(RECORDS),
+                    help="table-gradient records of the headline leg (mri_set_option bwd_records): f32 = the "
+                         "reference's precision; packed = 8-byte records, each contribution rounded to 18-21 bits")
+    ap.add_argument("--no-records-leg", action="store_true",
+                    help="skip the second timed leg with the other record format")
     ap.add_argument("--grad-buckets", type=int, default=0,
                     help="level groups of the table-gradient kernels (0 = default)")
     args = ap.parse_args()
@@ -298,13 +325,29 @@ def main():
     import torch
     from mri_interpolation_amd import _lib, datamodules, parallel, trainer
     _lib.load()  # no fallback: fail before touching the GPU if the HIP library is missing
-    for item in args.opt:
+
+    _lib.set_option("bwd_records", RECORDS[args.records][0])
+    for item in args.opt:  # (after --records: an explicit bwd_records=2 selects round 1's layout for A/B runs)
         name, value = item.split("=")
         _lib.set_option(name, int(value))
 
     rank, world, local = parallel.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+    dist_info = None
+    if world > 1:
+        import torch.distributed as dist
+        dist_info = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
+                         rccl=".".join(map(str, torch.cuda.nccl.version()))
+                         if dist.get_backend() == "nccl" else None)
+        # a multi-GPU line must be an RCCL line with every rank present: anything else fails HERE
+        if dist_info["ranks"] != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist_info['ranks']} ranks")
+        if dist_info["backend"] != "nccl" and not args.allow_gloo:
+            raise SystemExit(f"--gpus {args.gpus}: backend is '{dist_info['backend']}', not nccl (RCCL); "
+                             "a CPU / one-GPU rehearsal must say --allow-gloo")
+        if dist_info["backend"] == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     w = WORKLOADS[args.workload]
@@ -325,7 +368,8 @@ def main():
     opt = model.configure_optimizers()
     step = trainer.FusedStep(model, opt, world)
     step.bwd_method = args.bwd_method
-    step.dp_mode = args.dp_mode
+    if args.dp_mode != "auto":
+        step.dp_mode = args.dp_mode
     step.overlap_forward = args.overlap_forward
     step.fuse_table_adam = args.fused_adam
     if args.no_count_ahead:
@@ -342,6 +386,7 @@ def main():
     counter = [0]
     events = {}
     sampling = [False]
+    leg_start = [0]
     # shuffled batches, epoch after epoch; batch k+1 is produced while step k runs (queued on
     # the step's side stream, or after Adam when the step has none): its kernels still execute
     # inside the timed region
@@ -350,7 +395,7 @@ def main():
     def one_step():
         k = counter[0]
         counter[0] += 1
-        step.phase_events = events if sampling[0] and (k - args.warmup) % max(1, args.phase_every) == 0 \
+        step.phase_events = events if sampling[0] and (k - leg_start[0]) % max(1, args.phase_every) == 0 \
             else None
         coords, target = pipe.current()
         if args.no_prefetch:
@@ -361,21 +406,167 @@ def main():
         pipe.advance()
         return loss
 
-    for _ in range(args.warmup):
-        one_step()
-    sampling[0] = True
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3  # time to QUEUE a step (host side)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
-    step.phase_events = events
-    phases = step.phase_ms()
-    step.phase_events, sampling[0] = None, False
+    def timed_leg(warmup, steps):
+        """`warmup` untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both
+        sides; returns seconds (max over ranks), per-phase ms, host ms per step, the last loss."""
+        events.clear()
+        sampling[0] = False
+        for _ in range(warmup):
+            one_step()
+        sampling[0], leg_start[0] = True, counter[0]
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = one_step()
+        host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to QUEUE a step (host side)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+        step.phase_events = events
+        phases = step.phase_ms()
+        step.phase_events, sampling[0] = None, False
+        if hasattr(step, "check_status"):
+            step.check_status()  # the overlapped decoder's wait for the lookup must never have timed out
+        return dict(elapsed=elapsed, phases=phases, host_ms=host_ms, loss=float(loss),
+                    ms_per_step=elapsed / steps * 1e3, value=w["batch"] * world * steps / elapsed)
+
+    def replicas_identical():
+        """Data parallel: every rank must hold the same parameters, bit for bit."""
+        if world == 1:
+            return True
+        import torch.distributed as dist
+        c = step.flat.param.double().sum().reshape(1)
+        lo_, hi_ = c.clone(), c.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        return bool((lo_ == hi_).item())
+
+    # ---- the timed legs.  One GPU: the headline leg.  Several: the gradient-exchange variants, back to
+    # back in ONE invocation so that a single scaling pass measures them all (the plain all-reduce first:
+    # whatever happens in the others, its line exists); `value` is the fastest leg whose replicas stayed
+    # identical, and config.parallelism names it.
+    if world == 1:
+        plan = [("single", None, None)]
+    elif args.dp_mode == "auto":
+        plan = [("all_reduce_1", "all_reduce", 1), ("all_reduce_4", "all_reduce", 4),
+                ("reduce_scatter", "reduce_scatter", 1)]
+    else:
+        plan = [(args.dp_mode + (f"_{step.grad_buckets}" if args.dp_mode == "all_reduce" else ""),
+                 args.dp_mode, step.grad_buckets)]
+    legs, partial_line = {}, [None]
+    watchdog = None
+    if world > 1 and len(plan) > 1:
+        import threading
+
+        def give_up():  # a later leg hangs in its first contact with RCCL: keep the line we have
+            if rank == 0 and partial_line[0] is not None:
+                partial_line[0]["aborted"] = "a later gradient-exchange leg did not finish within " \
+                                             f"{args.leg_timeout} s; this line holds the legs that did"
+                print(json.dumps(partial_line[0]), flush=True)
+            os._exit(0 if partial_line[0] is not None or rank != 0 else 3)
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+
+    def finish(best_name, psnr=None, packed=None, cpu=None):
+        """The result line from the legs measured so far (rank 0)."""
+        best = legs[best_name]
+        phases = best["phases"]
+        pm = phase_model(w, step, n_params)
+        rooflines = {}
+        for name in sorted(k for k in phases if k in pm):
+            bound, amount = pm[name]
+            sec = phases[name] * 1e-3
+            if bound == "hbm":
+                r = dict(bound="hbm", achieved=amount / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            else:
+                r = mfma_roof(step, amount / sec / 1e12)
+            r.update(frac=r["achieved"] / r["peak"], traffic=pmc_traffic(args.workload, name, args.records),
+                     ms_per_launch=phases[name])
+            rooflines[name] = r
+        dominant = max(rooflines, key=lambda k: phases[k])
+        roof = dict(rooflines[dominant], kernel=dominant)
+        mode = best.get("dp_mode")
+        result = {
+            "metric": "coord-samples/sec (train)", "value": best["value"], "unit": "coord-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "arithmetic": arithmetic(args.records), "records": args.records,
+            "data": data_name,
+            "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} "
+                                   f"{'sample volume' if w.get('sample_volume') else 'analytic phantom'}"
+                                   f", {w['model']}, batch {w['batch']} coords per GPU"
+                                   + (", even frames trained, odd frames held out"
+                                      if w.get("holdout") else ""),
+                       "global_batch": w["batch"] * world, "params": n_params,
+                       "parallelism": (f"dp{world} z-slab, {mode}"
+                                       + (f", {best['grad_buckets']} level group(s)"
+                                          if mode == "all_reduce" else ""))
+                       if world > 1 else "single GPU"},
+            "roofline": roof,
+            "rooflines": rooflines,
+            "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
+            "phases_sampled_every": max(1, args.phase_every),
+            "host_queue_ms_per_step": round(best["host_ms"], 4),
+            "final_loss": best["loss"],
+        }
+        if world > 1:  # what the first real multi-GPU run needs to explain itself
+            result["collectives"] = {
+                "backend": dist_info["backend"], "ranks_seen": dist_info["ranks"],
+                "rccl_version": dist_info["rccl"],
+                "exposed_ms_per_step": round(phases.get("all_reduce", 0.0), 4),
+                "note": "exposed = the compute stream's wait for the reductions + per-group Adam "
+                        "(phases_ms.all_reduce contains the Adam launches, phases_ms.adam is absent); "
+                        "legs[*].groups: bytes of each reduction and the compute stream's wait for it",
+                "legs": {k: {"ms_per_step": round(v["ms_per_step"], 4), "value": v["value"],
+                             "dp_mode": v["dp_mode"], "grad_buckets": v["grad_buckets"],
+                             "replicas_identical": v["identical"],
+                             "exposed_ms_per_step": round(v["phases"].get("all_reduce", 0.0), 4),
+                             "groups": v["groups"]} for k, v in legs.items()}}
+        if step.encoder is not None:  # whole-step HBM fraction as north_star defines it (SURVEY 8d)
+            e = step.encoder
+            per_coord = 4 * e.dim + 4 + 2 * (1 << e.dim) * e.output_dim * 4 + 28.0 * n_params / w["batch"]
+            result["step_hbm_frac"] = best["value"] / world * per_coord / (HBM_PEAK_GBS * 1e9)
+        if packed is not None:
+            result["packed_records"] = packed
+        if psnr is not None:
+            result["psnr"] = psnr
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+        return result
+
+    def best_leg():
+        ok = [k for k, v in legs.items() if v["identical"]]
+        if not ok:
+            raise SystemExit("no gradient-exchange leg kept the replicas identical: " + json.dumps(
+                {k: v["identical"] for k, v in legs.items()}))
+        return max(ok, key=lambda k: legs[k]["value"])
+
+    for i, (name, mode, buckets) in enumerate(plan):
+        if mode is not None:
+            step.dp_mode, step.grad_buckets, step._bucket_cache = mode, buckets, None
+        if i == 1 and watchdog is not None:
+            watchdog.start()
+        try:
+            leg = timed_leg(args.warmup, args.steps)
+        except Exception as exc:  # a variant may be refused (e.g. shards that do not divide): say so
+            if i == 0:
+                raise
+            legs[name] = dict(error=repr(exc), identical=False, value=0.0, ms_per_step=0.0, phases={}, groups=[],
+                              dp_mode=mode, grad_buckets=buckets, host_ms=0.0, loss=float("nan"))
+            continue
+        leg.update(dp_mode=mode, grad_buckets=buckets, identical=replicas_identical(),
+                   groups=[dict(bytes=b, wait_ms=round(leg["phases"].get(f"reduce_wait_{j}", 0.0), 4))
+                           for j, b in enumerate(getattr(step, "last_group_bytes", []))]
+                   if world > 1 else [])
+        legs[name] = leg
+        if rank == 0 and world > 1:
+            partial_line[0] = finish(best_leg()) if any(v["identical"] for v in legs.values()) else None
+    if watchdog is not None:
+        watchdog.cancel()
+    best = best_leg()
+    if world > 1:  # continue (PSNR steps) in the mode the line reports
+        step.dp_mode, step.grad_buckets, step._bucket_cache = legs[best]["dp_mode"], legs[best]["grad_buckets"], None
 
     # PSNR vs ground-truth voxels at a fixed step count (outside the timed region)
     psnr = None
@@ -406,68 +597,26 @@ def main():
                 if linear is not None:
                     psnr["heldout_linear_interp_db"] = trainer.psnr(linear.reshape(-1, 1),
                                                                     odd.pixels)
-    dist_info = None
+    # the other record format beside the headline (one GPU, grids with two features per level): the same
+    # model and loader, the same number of timed steps
+    packed = None
+    if (world == 1 and step.encoder is not None and step.encoder.n_features_per_level == 2
+            and not args.no_records_leg and args.bwd_method != 1):
+        other = "packed" if args.records == "f32" else "f32"
+        _lib.set_option("bwd_records", RECORDS[other][0])
+        leg = timed_leg(min(args.warmup, 20), args.steps)
+        _lib.set_option("bwd_records", RECORDS[args.records][0])
+        packed = dict(records=other, value=leg["value"], ms_per_step=leg["ms_per_step"],
+                      phases_ms={k: round(v, 4) for k, v in sorted(leg["phases"].items())},
+                      arithmetic=RECORDS[other][1])
     if world > 1:  # leave the process group together (rank 0 was busy with the PSNR pass)
         import torch.distributed as dist
-        dist_info = dict(backend=dist.get_backend(), ranks=dist.get_world_size(),
-                         rccl=".".join(map(str, torch.cuda.nccl.version()))
-                         if dist.get_backend() == "nccl" else None)
         parallel.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
-
-    ms = elapsed / args.steps * 1e3
-    value = w["batch"] * world * args.steps / elapsed
-    pm = phase_model(w, step, n_params)
-    dominant = max((k for k in phases if k in pm), key=lambda k: phases[k])
-    bound, amount = pm[dominant]
-    sec = phases[dominant] * 1e-3
-    if bound == "hbm":
-        roof = dict(bound="hbm", achieved=amount / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-    else:
-        roof = mfma_roof(step, amount / sec / 1e12)
-    roof.update(frac=roof["achieved"] / roof["peak"], traffic=pmc_traffic(args.workload, dominant),
-                kernel=dominant, ms_per_launch=phases[dominant])
-    result = {
-        "metric": "coord-samples/sec (train)", "value": value, "unit": "coord-samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "arithmetic": ARITHMETIC,
-        "data": data_name,
-        "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} "
-                               f"{'sample volume' if w.get('sample_volume') else 'analytic phantom'}"
-                               f", {w['model']}, batch {w['batch']} coords per GPU"
-                               + (", even frames trained, odd frames held out"
-                                  if w.get("holdout") else ""),
-                   "global_batch": w["batch"] * world, "params": n_params,
-                   "parallelism": (f"dp{world} z-slab, {args.dp_mode}"
-                                   + (f", {step.grad_buckets} level groups"
-                                      if args.dp_mode == "all_reduce" else ""))
-                   if world > 1 else "single GPU"},
-        "roofline": roof,
-        "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
-        "phases_sampled_every": max(1, args.phase_every),
-        "host_queue_ms_per_step": round(host_ms, 4),
-        "final_loss": float(loss),
-    }
-    if world > 1:  # what the first real multi-GPU run needs to explain itself
-        import torch.distributed as dist
-        result["collectives"] = {
-            "backend": dist_info["backend"], "ranks_seen": dist_info["ranks"],
-            "rccl_version": dist_info["rccl"],
-            "exposed_ms_per_step": round(phases.get("all_reduce", 0.0), 4),
-            "note": "exposed = wait for the reductions + per-group Adam on the compute stream "
-                    "(phases_ms.all_reduce; it contains the Adam launches, phases_ms.adam is absent)"}
-    if step.encoder is not None:  # whole-step HBM fraction as north_star defines it
-        e = step.encoder
-        per_coord = 4 * e.dim + 4 + 2 * (1 << e.dim) * e.output_dim * 4 + 28.0 * n_params / w["batch"]
-        result["step_hbm_frac"] = value / world * per_coord / (HBM_PEAK_GBS * 1e9)
-    if psnr is not None:
-        result["psnr"] = psnr
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(w, args.workload)
-    print(json.dumps(result), flush=True)
+    cpu = cpu_baseline(w, args.workload) if world == 1 and not args.no_cpu_baseline else None
+    print(json.dumps(finish(best, psnr, packed, cpu)), flush=True)
 
 
 if __name__ == "__main__":

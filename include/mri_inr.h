@@ -71,7 +71,13 @@ const char* mri_last_error(void);
  * "bwd_dense_max_parts" n, "bwd_dense_blocks" n, "bwd_fuse_dense" 0/1, "fwd_pair" 0/1,
  * "mlp_stagger" 0..8, "mlp_x3" 0/1/2: which kernel serves the decoder -- 1 (default) the bf16-pipe
  * kernel with exact three-term operands, 2 its four-wave form (128-wide), 0 the f32-MFMA kernels);
- * results stay within fp32 summation-order noise. */
+ * results stay within fp32 summation-order noise.
+ * ONE option trades accuracy, for grids with two features per level: "bwd_records" 0 (default) / 1,
+ * the gradient records of mri_hashgrid_backward* (see there).  0: every contribution w * g is the f32
+ * product the reference's autograd forms, their sum per table entry is exact.  1: each contribution is
+ * rounded to 18-21 significant bits (8-byte packed records) before the exact sum -- 13 us faster per
+ * step at BASELINE config 4 and NOT f32-equivalent (per table entry 17x the median error of the f32
+ * records against float64, tests/test_gpu_round3.py). */
 int mri_set_option(const char* name, int32_t value);
 
 /* ---- hash-grid encoding --------------------------------------------------------------
@@ -96,6 +102,13 @@ int mri_hashgrid_forward(const mri_grid_desc* grid, const float* x, int64_t n,
  * three-stride addressing as `out` above.
  *   method 0 = choose per level; 1 = global float atomics; 2 = LDS owner-computes scan with
  *   64-bit fixed-point accumulation (bitwise reproducible gradients).
+ *   Accuracy of methods 0 / 2 (the binned path): the contributions of a table entry are added as
+ *   integers in units of 2^-e, e chosen per level so that n * max|d_out| * 2^e < 2^61: the sum is exact
+ *   but for what lies below that unit -- a contribution smaller than 2^-40 of the level's max |d_out|
+ *   (n = 2^18; 2^-(58 - log2 n) in general) is truncated toward zero, so an entry whose only
+ *   contributions are that small reads 0 where the reference holds a denormal-scale value.  With
+ *   mri_set_option("bwd_records", 1) each contribution is first rounded to 18-21 significant bits and
+ *   the cut-off is 2^-45 of the level's maximum (2^(E-45), E the exponent of max |d_out|).
  *   workspace: device scratch of at least mri_hashgrid_backward_workspace_bytes(grid, n)
  *   bytes, 16-byte aligned; no initialisation needed (the call clears what it needs), it
  *   may be shared by calls with different grids / n on the same stream.  May be NULL for

@@ -35,7 +35,8 @@ inline int check_launch(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Tuning knobs (process-wide, speed only -- never change results beyond fp32 summation order).
+// Tuning knobs (process-wide, speed only -- never change results beyond fp32 summation order), with ONE
+// exception that trades accuracy: bwd_records.
 struct Options {
   int xcd_affinity = 1;       // map hash-grid levels to XCDs (blockIdx % 8) so a level's table stays in one L2
   int bwd_lds_max_parts = 256;    // levels cut into more LDS slices than this use global atomics
@@ -46,6 +47,10 @@ struct Options {
   int bwd_fuse_dense = 1;         // dense levels share the launch of the record accumulation (fills its last round)
   int bwd_dense_blocks = 96;      // workgroups of the dense-level launch (all dense levels together)
   int bwd_dense_max_parts = 4;    // levels with at most this many table slices skip the records (measured optimum)
+  // Table-gradient records of grids with two features per level (hashgrid_bwd.hip): 0 = f32 products
+  // (the reference's precision: f32 products, here even summed exactly); 1 = packed 8-byte records, every
+  // product rounded to 18-21 significant bits before the exact sum (13 us faster at config 4, NOT f32).
+  int bwd_records = 0;
 };
 Options& options();
 

@@ -33,6 +33,7 @@
 // 2 + 4 F bytes (16-bit slot + F float values).
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "hashgrid_common.h"
 
@@ -136,8 +137,22 @@ __device__ __forceinline__ long long to_fixed(float v, float scale_hi) {
 // gradient stays bitwise reproducible; per record it is rounded to those 18-21 bits (the tests' 1e-5 is
 // on the level's largest gradient, where the rounding is 2.4e-7).  Plain 24-bit fixed point would lose
 // every contribution below 2^-23 of the level's maximum, which Adam, scale-free per parameter, still sees.
+// Record formats of the binned path.  Grids with two features per level choose at RUN time
+// (mri_set_option("bwd_records", ...), read per call):
+//   kRecSoA    (option 0, default, and every other F) 16-bit slot + F f32 values in F + 1 arrays: the
+//              products are the f32 values the reference's autograd forms (encoding.py:127-128), and their
+//              sum is exact -- at least the reference's precision;
+//   kRecPacked (option 1, F = 2) the 8-byte word above: each product rounded to 18-21 significant bits
+//              first (17x the median per-slot error of the f32 records, 31x the rms, measured against
+//              float64: tests/test_gpu_round3.py), 13 us faster at BASELINE config 4.
+// (Round 3 also built 12-byte records {slot, f32, f32} -- one staged store, one 12-byte global store and
+// 16- or 12-byte loads per record, exact like kRecSoA: scatter 81 us against 76, accumulate 132 (151 with
+// 12-byte loads) against 86 on one box: 96-bit LDS and global accesses are the slow path here.  Removed.)
+enum RecFmt { kRecSoA = 0, kRecPacked = 1 };
 template <int F>
-constexpr bool kPackedRecords = (F == 2);
+inline int record_format() {
+  return F == 2 && options().bwd_records == 1 ? kRecPacked : kRecSoA;
+}
 static_assert(kAccWords / 2 <= 8192, "packed records hold the slot within a slice in 13 bits");
 __device__ __forceinline__ int level_E(uint32_t max_bits) { return (int)((max_bits >> 23) & 255u) - 127; }
 __device__ __forceinline__ int rec_exponent(uint32_t max_bits) {  // es0
@@ -198,7 +213,6 @@ __device__ __forceinline__ void wave_exclusive_scan(const uint32_t* in, uint32_t
 // their 16 corners are then split over 2 (4) threads instead of leaving half the workgroup idle
 template <int D, int F>
 struct BinGeometry {
-  static constexpr int rec_words = kPackedRecords<F> ? 2 : 1 + F;  // staged words per record
   static constexpr int per_coord = (1 << D) * (1 + F);
   static constexpr int coords = kStageWords / per_coord / 64 * 64 < kBinThreads
                                     ? kStageWords / per_coord / 64 * 64 : kBinThreads;
@@ -222,7 +236,7 @@ __device__ __forceinline__ int xcd_chunk() {
 // ------------------------------------------------------------------------ 2. count / 4. scatter
 // One workgroup = (chunk of coords_per_block coordinates, level).  Both kernels walk the same
 // corners in the same way; `SCATTER` selects what is done with them.
-template <int D, int F, bool SCATTER>
+template <int D, int F, bool SCATTER, int R = kRecSoA>
 __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     const LevelTab tab, const BinPlan plan, const float* __restrict__ x,
     const float* __restrict__ d_out, int64_t n, int64_t sl, int64_t sr, int64_t sf,
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
   // (packed records: 8 instead of 12 bytes per corner -> 32 KiB, four workgroups per CU)
-  __shared__ __attribute__((aligned(16))) uint32_t stage[SCATTER ? (kPackedRecords<F> ? kStageWords * 2 / 3 : kStageWords) : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[SCATTER ? (R == kRecPacked ? kStageWords * 2 / 3 : kStageWords) : 1];
   __shared__ uint32_t wg_max;
 
   const int e = blockIdx.y;
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if constexpr (kPackedRecords<F>) {
+  if constexpr (R == kRecPacked) {
     // one 8-byte word per record (pack_record): one scattered LDS store here, one read and ONE global
     // store in the copy-out, one load in the accumulate kernel -- a third of the 2 + 4 + 4-byte form's
     // LDS conflict cycles and store instructions, which is where this kernel's time goes (4.2)
@@ -368,45 +382,53 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       for (uint32_t k = lane; k < cnt; k += 64) rec[dst + k] = stage2[lo + k];
     }
   } else {
-    float gmax = 0.0f;  // max |g| seen by this thread: feeds the level's fixed-point scale
+    // f32 records.  max |g| seen by this thread feeds the level's fixed-point scale, which only the
+    // accumulate launch needs -- unless the caller supplied the maxima (max_bits == nullptr here)
+    float gmax = 0.0f;
     if (live) {
-      const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
       for (int f = 0; f < F; ++f) gmax = fmaxf(gmax, fabsf(g[f]));
-#pragma unroll
-      for (int q = 0; q < G::corners; ++q) {
-        const int nb = sub * G::corners + q;
-        uint32_t h;
-        float w;
-        corner<D>(c, nb, h, w);
-        const uint32_t slot = slot_of(h, size, magic, pow2);
-        const uint32_t p = slot >> plan.log2_slots;
-        const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
-        stage[pos] = slot & slot_mask;
-#pragma unroll
-        for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
-      }
     }
+    if (max_bits != nullptr) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
-    // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
-    // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
-    if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
-    __syncthreads();
-    BWDP(4)
-    if (threadIdx.x == 0 && wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(max_bits + level, wg_max);
+      for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
+      // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
+      // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
+      if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
+    }
+    {
+      if (live) {
+        const Cell<D> c = locate<D>(xi, 0, res);
+#pragma unroll
+        for (int q = 0; q < G::corners; ++q) {
+          const int nb = sub * G::corners + q;
+          uint32_t h;
+          float w;
+          corner<D>(c, nb, h, w);
+          const uint32_t slot = slot_of(h, size, magic, pow2);
+          const uint32_t p = slot >> plan.log2_slots;
+          const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+          stage[pos] = slot & slot_mask;
+#pragma unroll
+          for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
+        }
+      }
+      __syncthreads();
+      BWDP(4)
+      if (max_bits != nullptr && threadIdx.x == 0 &&
+          wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(max_bits + level, wg_max);
 
-    // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
-    for (int p = wave; p < parts; p += kBinThreads / 64) {
-      const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
-      const uint64_t dst = (uint64_t)global_base[p];
-      for (uint32_t k = lane; k < cnt; k += 64) {
-        rec_slot[dst + k] = (uint16_t)stage[lo + k];
+      // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
+      for (int p = wave; p < parts; p += kBinThreads / 64) {
+        const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+        const uint64_t dst = (uint64_t)global_base[p];
+        for (uint32_t k = lane; k < cnt; k += 64) {
+          rec_slot[dst + k] = (uint16_t)stage[lo + k];
 #pragma unroll
-        for (int f = 0; f < F; ++f)
-          rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
+          for (int f = 0; f < F; ++f)
+            rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
+        }
       }
     }
   }
@@ -499,7 +521,7 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& a, uint64_t idx, floa
 }
 
 // ------------------------------------------------------------------------------ 5. accumulate
-template <int F>
+template <int F, int R>
 __device__ __forceinline__ void bin_accumulate_body(
     unsigned long long* __restrict__ acc, int b, const LevelTab& tab, const BinPlan& plan,
     int64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
@@ -530,7 +552,7 @@ __device__ __forceinline__ void bin_accumulate_body(
   }
 
   BWDA(0) BWDA(1)
-  // packed records: two sets of kGroups x 4 records per lane, the next set's loads in flight while this
+  // packed records: two sets of kPG x 4 records per lane, the next set's loads in flight while this
   // one's values go into LDS -- and the first set requested BEFORE the slice is zeroed: with one
   // workgroup per CU every latency a workgroup waits out is idle CU time (tools/bwd_segments.py)
   constexpr int kPG = 2;
@@ -548,7 +570,7 @@ __device__ __forceinline__ void bin_accumulate_body(
       }
     }
   };
-  if constexpr (kPackedRecords<F>) load_set(0, k_lo + 4 * threadIdx.x);
+  if constexpr (R == kRecPacked) load_set(0, k_lo + 4 * threadIdx.x);
   for (uint32_t s = threadIdx.x; s < count * F; s += kAccThreads) acc[s] = 0ull;
   // fused Adam: this slice's parameters and moments are fetched NOW, before the record phase (read at
   // the end they would add their full HBM latency to every workgroup: 0.21 -> 0.28 ms measured)
@@ -571,7 +593,7 @@ __device__ __forceinline__ void bin_accumulate_body(
   BWDA(2)
   const int ex = level_exponent(max_bits[level], n);
   const float scale_hi = __builtin_ldexpf(1.0f, ex - 32);
-  if constexpr (kPackedRecords<F>) {
+  if constexpr (R == kRecPacked) {
     // packed 8-byte records (pack_record): value = m 2^-(es0 + 4 c), accumulator unit 2^-ex: a shift by
     // ex - es0 - 4 c (44 - log2 n - 4 c)
     const int sh = ex - rec_exponent(max_bits[level]);  // for class 0; 4 less per class
@@ -605,7 +627,6 @@ __device__ __forceinline__ void bin_accumulate_body(
     // kGroups such loads per array in flight before the first LDS atomic: the kernel is latency
     // bound (78 % of wave cycles in s_waitcnt), not LDS bound
     constexpr int kGroups = 4;
-    const uint32_t k_vec = k_lo + ((k_hi - k_lo) & ~3u);
     const uint16_t* __restrict__ slot_ptr = rec_slot + (uint64_t)r_lo;
     const float* __restrict__ val_ptr = rec_val + (uint64_t)r_lo;
     for (uint32_t k0 = k_lo + 4 * threadIdx.x; k0 < k_vec; k0 += 4 * kAccThreads * kGroups) {
@@ -694,7 +715,7 @@ __device__ __forceinline__ void bin_accumulate_body(
 #endif
 }
 
-template <int F>
+template <int F, int R>
 __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const LevelTab tab, const BinPlan plan, int64_t n, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ counts, const uint16_t* __restrict__ rec_slot,
@@ -702,8 +723,8 @@ __global__ __launch_bounds__(kAccThreads) void bin_accumulate_kernel(
     const uint32_t* __restrict__ max_bits, float* __restrict__ d_table,
     unsigned long long* __restrict__ partial, int overwrite, const AdamFuse ad) {
   __shared__ unsigned long long acc[kAccWords];
-  bin_accumulate_body<F>(acc, blockIdx.x, tab, plan, n, offsets, counts, rec_slot, rec_val,
-                         records, max_bits, d_table, partial, overwrite, ad);
+  bin_accumulate_body<F, R>(acc, blockIdx.x, tab, plan, n, offsets, counts, rec_slot, rec_val,
+                            records, max_bits, d_table, partial, overwrite, ad);
 }
 
 // ------------------------------------------------------------------------- coarse levels
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(kAccThreads) void dense_level_kernel(
 // 128 KiB of LDS).  The accumulate workgroups of BASELINE config 4 (820 on 256 CUs) leave their
 // fourth round 80 % empty and the dense launch (192 workgroups) leaves a quarter of the CUs idle;
 // together they fill four rounds, the (longer) dense workgroups first.
-template <int D, int F>
+template <int D, int F, int R>
 __global__ __launch_bounds__(kAccThreads) void dense_and_accumulate_kernel(
     const LevelTab tab, const BinPlan dense, int dense_blocks, const BinPlan plan,
     const float* __restrict__ x, const float* __restrict__ d_out, int64_t n, int64_t sl,
@@ -868,8 +889,8 @@ __global__ __launch_bounds__(kAccThreads) void dense_and_accumulate_kernel(
   if (b < dense_blocks)
     dense_level_body<D, F>(acc, b, tab, dense, x, d_out, n, sl, sr, sf, max_bits, partial);
   else
-    bin_accumulate_body<F>(acc, b - dense_blocks, tab, plan, n, offsets, counts, rec_slot,
-                           rec_val, records, max_bits, d_table, partial, overwrite, ad);
+    bin_accumulate_body<F, R>(acc, b - dense_blocks, tab, plan, n, offsets, counts, rec_slot,
+                              rec_val, records, max_bits, d_table, partial, overwrite, ad);
 }
 
 // ------------------------------------------------------------------------------ 6. finalize
@@ -978,9 +999,12 @@ int64_t chunk_table_words(const BinPlan& plan, int64_t n) {
   return (int64_t)plan.total_bins * chunks + 4;
 }
 
+// bytes per record of the largest format the grid may choose at run time (16-bit slot + F f32 values)
+inline int64_t record_bytes(int F) { return 2 + 4 * F; }
+
 int64_t workspace_bytes(const BinPlan& plan, int64_t n, int64_t ws_words, int64_t records, int F) {
   return (int64_t)kHeaderWords * 4 + 2 * (int64_t)kMaxBins * 4 + (int64_t)(kMaxBins + 1) * 4 + 12 +
-         2 * chunk_table_words(plan, n) * 4 + ws_words * 8 + records * (2 + 4 * F) + 80;
+         2 * chunk_table_words(plan, n) * 4 + ws_words * 8 + records * record_bytes(F) + 80;
 }
 
 // Fixed-position regions first, the record area next, the int64 area at the END of the buffer.
@@ -1058,8 +1082,10 @@ struct BinnedLaunch {
       // dense levels: their launch is merged with the record accumulation when the call has both
       const bool fuse_dense = dense.n_entries > 0 && sel.n_entries > 0 && options().bwd_fuse_dense;
       // max |d_out| per level (float bit patterns): the workspace header, filled by a pass over d_out -- or,
-      // packed records only, the caller's array (the decoder kernel that produced d_out knows it already)
-      const bool given = ext_max != nullptr && kPackedRecords<F>;
+      // two features per level (feature pair = level), the caller's array (the decoder kernel that produced
+      // d_out knows it already)
+      const int fmt = record_format<F>();
+      const bool given = ext_max != nullptr && F == 2;
       uint32_t* const mx = given ? const_cast<uint32_t*>(ext_max) : w.max_bits;
       if (dense.n_entries > 0 && phase != 1 && !fuse_dense) {
         if (!given)
@@ -1110,7 +1136,7 @@ struct BinnedLaunch {
       uint32_t absmax_levels = 0;  // with the fused launch: dense absmax rides on the scatter grid
       if (fuse_dense)
         for (int e = 0; e < dense.n_entries; ++e) absmax_levels |= 1u << dense.level_of[e];
-      if constexpr (kPackedRecords<F>) {
+      if (fmt == kRecPacked || given) {
         // packed records are scaled by their level's max |g|, which must therefore be complete before the
         // scatter stages its first record: one pass over d_out for the binned (and fused dense) levels
         BinPlan both{};
@@ -1119,24 +1145,38 @@ struct BinnedLaunch {
         if (!given)
           hipLaunchKernelGGL((dense_absmax_kernel<F>), dim3(64, both.n_entries), dim3(256), 0, st, both, d_out,
                              n, sl, sr, sf, mx);
-        absmax_levels = 0;
+        absmax_levels = 0;  // (f32 records with the maxima given: the scatter has none to find)
       }
-      hipLaunchKernelGGL((bin_kernel<D, F, true>),
-                         dim3((unsigned)chunks, sel.n_entries + (fuse_dense && !kPackedRecords<F> ? dense.n_entries : 0)),
-                         dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
-                         w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
-                         w.records, mx, absmax_levels);
-      if (fuse_dense)
-        hipLaunchKernelGGL((dense_and_accumulate_kernel<D, F>),
-                           dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
-                           tab, dense, dense_blocks, sel, x, d_out, n, sl, sr, sf, w.offsets,
-                           w.counts, w.rec_slot, w.rec_val, w.records, mx, d_table,
-                           w.partial, overwrite, ad);
-      else
-        hipLaunchKernelGGL((bin_accumulate_kernel<F>), dim3((unsigned)acc_blocks),
-                           dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts,
-                           w.rec_slot, w.rec_val, w.records, mx, d_table, w.partial,
-                           overwrite, ad);
+      auto launch = [&](auto fmt_tag) {
+        constexpr int R = decltype(fmt_tag)::value;
+        // f32 records: the scatter finds the maxima on the way (extra rows for the fused dense levels),
+        // unless they are given; packed records read them
+        uint32_t* const scatter_max = (R != kRecPacked && given) ? nullptr : mx;
+        const int extra_rows = (fuse_dense && R != kRecPacked && !given) ? dense.n_entries : 0;
+        hipLaunchKernelGGL((bin_kernel<D, F, true, R>), dim3((unsigned)chunks, sel.n_entries + extra_rows),
+                           dim3(kBinThreads), 0, st, tab, sel, x, d_out, n, sl, sr, sf,
+                           w.chunk_hist, w.chunk_base, w.offsets, chunks, w.rec_slot, w.rec_val,
+                           w.records, scatter_max, absmax_levels);
+        if (fuse_dense)
+          hipLaunchKernelGGL((dense_and_accumulate_kernel<D, F, R>),
+                             dim3((unsigned)(dense_blocks + acc_blocks)), dim3(kAccThreads), 0, st,
+                             tab, dense, dense_blocks, sel, x, d_out, n, sl, sr, sf, w.offsets,
+                             w.counts, w.rec_slot, w.rec_val, w.records, mx, d_table,
+                             w.partial, overwrite, ad);
+        else
+          hipLaunchKernelGGL((bin_accumulate_kernel<F, R>), dim3((unsigned)acc_blocks),
+                             dim3(kAccThreads), 0, st, tab, sel, n, w.offsets, w.counts,
+                             w.rec_slot, w.rec_val, w.records, mx, d_table, w.partial,
+                             overwrite, ad);
+      };
+      if constexpr (F == 2) {
+        if (fmt == kRecPacked)
+          launch(std::integral_constant<int, kRecPacked>{});
+        else
+          launch(std::integral_constant<int, kRecSoA>{});
+      } else {
+        launch(std::integral_constant<int, kRecSoA>{});
+      }
       finalize();
       return check_launch("hashgrid backward (binned)");
     } else {

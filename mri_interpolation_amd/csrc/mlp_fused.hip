@@ -40,11 +40,14 @@ constexpr int kThreads = 256;   // 4 waves
 // with relaxed agent-scope loads, then ONE agent-scope acquire (invalidates this CU's L1) and
 // its vmcnt(0); the caller's workgroup barrier follows, after which plain loads see the
 // producer's write-through stores.  The poll is bounded (~1 s): a producer that never runs must
-// not hang the GPU -- the kernel then finishes on garbage and reports through `status`.
+// not hang the GPU -- the kernel then finishes on garbage and reports through `status`.  The bound is
+// spent ONCE per launch: after any workgroup has given up, `status` is set and every later wait
+// (of every workgroup) returns at its first look instead of spinning out its own second.
 __device__ __forceinline__ void wait_slice(const FusedArgs& a, int64_t slice) {
   int spins = 0;
   while (__hip_atomic_load(a.ready + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
          a.ready_target) {
+    if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     __builtin_amdgcn_s_sleep(8);
     if (++spins > (1 << 22)) {
       __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

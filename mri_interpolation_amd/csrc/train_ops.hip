@@ -201,6 +201,9 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
     options().mlp_x3 = value;
   } else if (!strcmp(name, "mlp_stagger")) {
     options().mlp_stagger = value;
+  } else if (!strcmp(name, "bwd_records")) {
+    MRI_REQUIRE(value == 0 || value == 1, "bwd_records %d not in {0, 1}", value);
+    options().bwd_records = value;
   } else if (!strcmp(name, "bwd_blocks_per_level")) {
     options().bwd_blocks_per_level = value < 1 ? 1 : value;
   } else {

@@ -99,15 +99,20 @@ class FusedStep:
         # Data parallel: the table gradient is produced level by level, so its reduction is cut
         # into `grad_buckets` level groups; group g's all-reduce (RCCL, its own stream) runs
         # while group g+1's gradient is still being computed.  1 = one reduction at the end.
-        self.grad_buckets = 1 if world == 1 else 4
+        # Default 1 for every world size: the bucketed form (asynchronous all-reduces of slices of one flat
+        # buffer, per-group Adam behind each) has only ever met a one-rank RCCL communicator; it stays
+        # opt-in (`grad_buckets = 4`, bench.py times it as its own leg) until a real multi-GPU run has
+        # passed with it.
+        self.grad_buckets = 1
         self._bucket_cache = None
+        self.last_group_bytes = []  # bytes of each reduction of the last data-parallel step
         # "all_reduce": level-group all-reduces overlapped with the table-gradient kernels, every
         # rank steps the whole buffer.  "reduce_scatter": ONE reduce-scatter of the flat gradient,
         # each rank Adam-steps its 1/world shard (7/8 less optimiser traffic at 8 ranks), ONE
         # all-gather of the parameters -- same bytes on the links, but the all-gather sits between
         # Adam and the next forward pass instead of beside the gradient kernels (DESIGN.md
         # section 6); kept selectable so both can be timed on a real node.
-        self.dp_mode = "all_reduce"
+        self._dp_mode = "all_reduce"
         self.rank = parallel.env_world()[0] if world > 1 else 0
         # Single launch of the table gradient: its counting stage depends on the coordinates
         # only, so it is queued on a side stream and overlaps the forward pass / decoder.
@@ -155,6 +160,20 @@ class FusedStep:
         self._ready_key = None
         self._status = None
         self._overlapped = False
+
+    @property
+    def dp_mode(self) -> str:
+        return self._dp_mode
+
+    @dp_mode.setter
+    def dp_mode(self, mode: str):
+        """Refuse at configuration time what would otherwise fail inside the first step."""
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"dp_mode {mode!r}: all_reduce or reduce_scatter")
+        if mode == "reduce_scatter" and self.world > 1 and self.flat._grad_all.numel() % self.world:
+            raise ValueError(f"reduce_scatter: the flat buffer ({self.flat._grad_all.numel()} floats, padded to "
+                             f"256) does not divide over {self.world} ranks; use all_reduce")
+        self._dp_mode = mode
 
     def _tiny_mlp_plan(self):
         """Parameters for the single-kernel tiny MLP (csrc/mlp_fused.hip) if the decoder is
@@ -637,21 +656,26 @@ class FusedStep:
         if self.world > 1 and self.dp_mode == "reduce_scatter":
             with self._phase("all_reduce"):
                 all_grads = self.flat._grad_all
-                parallel.reduce_scatter_sum(all_grads, self.rank, self.world)
+                self.last_group_bytes = [all_grads.numel() * 4, all_grads.numel() * 4]  # scatter, gather
+                with self._phase("reduce_wait_0"):
+                    parallel.reduce_scatter_sum(all_grads, self.rank, self.world)
                 lo, hi = parallel.shard_range(all_grads.numel(), self.rank, self.world)
                 self.opt.begin_step()
                 self.opt.step_shard(lo, hi)
-                parallel.all_gather_shards(self.flat._param_all, self.rank, self.world)
+                with self._phase("reduce_wait_1"):
+                    parallel.all_gather_shards(self.flat._param_all, self.rank, self.world)
         elif self.world > 1 and self._pending:
             # decoder and table level groups are already in flight, in this order; each one is
             # stepped as soon as its sum has landed, beside the reductions still running (Adam is
             # elementwise: the pieces give bit for bit what one launch over the buffer gives)
             if not covers_exactly_once(self._pending, self.flat.numel):
                 raise RuntimeError("gradient groups do not cover the flat buffer exactly once")
+            self.last_group_bytes = [(hi - lo) * 4 for _, lo, hi in self._pending]
             with self._phase("all_reduce"):
                 self.opt.begin_step()
-                for handle, lo, hi in self._pending:
-                    parallel.wait_all([handle])
+                for i, (handle, lo, hi) in enumerate(self._pending):
+                    with self._phase(f"reduce_wait_{i}"):  # how long the compute stream stood still for it
+                        parallel.wait_all([handle])
                     self.opt.step_range(lo, hi)
         elif self._table_stepped:  # the table was stepped with its gradient: the rest of the buffer
             self._table_stepped = False
@@ -663,7 +687,8 @@ class FusedStep:
                     self.opt.step_range(t1, self.flat.numel)
         else:
             if self.world > 1:
-                with self._phase("all_reduce"):
+                self.last_group_bytes = [self.flat.grad.numel() * 4]
+                with self._phase("all_reduce"), self._phase("reduce_wait_0"):
                     parallel.all_reduce_sum(self.flat.grad)
             with self._phase("adam"):
                 self.opt.step()
@@ -677,7 +702,7 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
                  precision: int = 32, log_every: int = 0, distributed: bool = True,
-                 accumulate_grad_batches=None, dp_mode: str = "all_reduce"):
+                 accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1):
         """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
         each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
         does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
@@ -692,6 +717,7 @@ class Trainer:
         if dp_mode not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"dp_mode {dp_mode!r} not in ('all_reduce', 'reduce_scatter')")
         self.dp_mode = dp_mode  # how a data-parallel FusedStep exchanges gradients, see there
+        self.grad_buckets = int(grad_buckets)  # level groups of the table gradient's reduction, see there
         self.rank, self.world = 0, 1
         if distributed:
             rank, world, _ = parallel.env_world()
@@ -716,10 +742,13 @@ class Trainer:
             model.optimizer = opt
         try:
             self.fused = FusedStep(model, opt, self.world)
-            self.fused.dp_mode = self.dp_mode
         except ValueError:
             self.fused = None
             opt.flatten()
+        if self.fused is not None:  # (a refused dp_mode is the caller's error, not "model does not fuse")
+            self.fused.dp_mode = self.dp_mode
+            self.fused.grad_buckets = max(1, self.grad_buckets)
+
         return opt
 
     def _check_equal_steps(self, loader, device):
@@ -795,6 +824,8 @@ class Trainer:
                     done = True
                     break
             torch.cuda.synchronize()
+            if self.fused is not None and self.fused.overlap_forward:
+                self.fused.check_status()  # a decoder workgroup that gave up waiting invalidates the epoch
             self.throughput.append(seen * self.world / max(time.perf_counter() - t0, 1e-9))
             if done:
                 break

@@ -124,6 +124,45 @@ def encode(x: torch.Tensor, tables: Sequence[torch.Tensor],
     return torch.cat([level_lookup(x, t, r) for t, r in zip(tables, resolutions)], dim=-1)
 
 
+def level_slots_and_weights(x: torch.Tensor, table_size: int, resolution: Resolution):
+    """(slots (n, 2^D) int64, weights (n, 2^D) float32) of one level: the integer and f32 steps of
+    `level_lookup` up to, not including, the table access (encoding.py:108-126)."""
+    dim = x.shape[-1]
+    if isinstance(resolution, (int, float)):
+        pos = x * resolution
+    else:
+        pos = x * torch.tensor(list(resolution), dtype=torch.float32)
+    cell = pos.long()
+    frac = pos - cell.float()
+    cell, frac = cell.unsqueeze(-2), frac.unsqueeze(-2)
+    floor_side = corner_mask(dim).reshape((1,) * (x.dim() - 1) + (1 << dim, dim))
+    vertex = torch.where(floor_side, cell, cell + 1)
+    w = torch.where(floor_side, 1 - frac, frac).prod(dim=-1)
+    return hash_torch(vertex, table_size), w
+
+
+def table_gradient_f64(x: torch.Tensor, d_out: torch.Tensor, sizes: Sequence[int],
+                       resolutions: Sequence[Resolution], n_features: int):
+    """The float64 yardstick of the table gradient (autograd of encoding.py:127-128): per level,
+    (sum, sum of magnitudes, number) of the products w * g over the corners that hash to each slot, with the f32 weights
+    and f32 incoming gradients the reference's backward multiplies, but every product and every
+    addition in float64.  `sum of magnitudes` bounds what ANY f32 evaluation can lose to
+    cancellation: an f32 product is within 2^-24 of its magnitude.  d_out: (n, L * F)."""
+    out = []
+    for l, (t, r) in enumerate(zip(sizes, resolutions)):
+        slot, w = level_slots_and_weights(x, t, r)
+        g = d_out[:, l * n_features:(l + 1) * n_features].double()
+        contrib = w.double().unsqueeze(-1) * g.unsqueeze(-2)          # (n, 2^D, F)
+        flat_slot = slot.reshape(-1)
+        total = torch.zeros(t, n_features, dtype=torch.float64)
+        mag = torch.zeros(t, n_features, dtype=torch.float64)
+        total.index_add_(0, flat_slot, contrib.reshape(-1, n_features))
+        mag.index_add_(0, flat_slot, contrib.abs().reshape(-1, n_features))
+        count = torch.bincount(flat_slot, minlength=t)
+        out.append((total, mag, count))
+    return out
+
+
 def resolutions_for(dim, n_levels, log2_hashmap_size, base_resolution, finest_resolution):
     """(resolution argument per level for `encode`, table sizes)."""
     res, sizes = level_geometry(dim, n_levels, log2_hashmap_size,

@@ -51,7 +51,13 @@ def test_two_rank_fit_on_unequal_slabs(tmp_path):
         outs.append(out)
     assert [p.returncode for p in procs] == [0, 0], "\n".join(outs)
     report = json.load(open(tmp_path / "dp_fit.json"))
-    assert set(report) == {"hash", "hash_rs", "siren", "batchnorm"}
+    assert set(report) == {"hash", "hash_rs", "siren", "batchnorm", "union"}
+    # every gradient-exchange form of the fused step == one process on the concatenated batch
+    union = report.pop("union")
+    assert set(union) == {"all_reduce_1", "all_reduce_4", "reduce_scatter"}
+    assert union["all_reduce_4"]["groups"] > 2 and union["all_reduce_1"]["groups"] == 1
+    for kind, r in union.items():
+        assert r["grad_rel_err"] <= 1e-6 and r["param_rel_err"] <= 1e-5, (kind, r)
     for kind, r in report.items():
         assert r["replicas_identical"] and r["finite"] and r["moved"], (kind, r)
         assert r["batches_per_epoch"] == 4 and r["steps_min"] == r["steps_max"], (kind, r)
@@ -60,7 +66,7 @@ def test_two_rank_fit_on_unequal_slabs(tmp_path):
     assert report["siren"]["optimizer_steps"] == 8
 
 
-@pytest.mark.parametrize("dp_mode", ["all_reduce", "reduce_scatter"])
+@pytest.mark.parametrize("dp_mode", ["all_reduce", "reduce_scatter", "auto"])
 def test_bench_two_ranks_contract(tmp_path, dp_mode):
     """The driver's N > 1 launch of bench.py (one rank per GPU, RANK / WORLD_SIZE / MASTER_* from the
     environment), rehearsed with two ranks on the one GPU: ONE JSON line from rank 0 with the
@@ -76,7 +82,8 @@ def test_bench_two_ranks_contract(tmp_path, dp_mode):
                    MRI_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-             "--warmup", "2", "--workload", "cfg2", "--psnr-steps", "0", "--dp-mode", dp_mode],
+             "--warmup", "2", "--workload", "cfg2", "--psnr-steps", "0", "--dp-mode", dp_mode,
+             "--allow-gloo"],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -92,8 +99,17 @@ def test_bench_two_ranks_contract(tmp_path, dp_mode):
     assert len(lines) == 1 and not any(l.startswith("{") for l in outs[1].splitlines())
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 6
-    assert r["config"]["global_batch"] == 2 * (1 << 18) and dp_mode in r["config"]["parallelism"]
-    assert abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    assert r["config"]["global_batch"] == 2 * (1 << 18)
     c = r["collectives"]
+    if dp_mode == "auto":  # what the driver's scaling pass runs: all three exchange forms, back to back
+        assert set(c["legs"]) == {"all_reduce_1", "all_reduce_4", "reduce_scatter"}
+        assert all(v["replicas_identical"] for v in c["legs"].values()), c["legs"]
+        assert r["value"] == max(v["value"] for v in c["legs"].values())
+        assert len(c["legs"]["all_reduce_4"]["groups"]) > 2 and len(c["legs"]["all_reduce_1"]["groups"]) == 1
+    else:
+        assert dp_mode in r["config"]["parallelism"] and len(c["legs"]) == 1
+    for leg in c["legs"].values():
+        assert all(g["bytes"] > 0 and g["wait_ms"] >= 0.0 for g in leg["groups"]), leg
+    assert abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
     assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["exposed_ms_per_step"] >= 0.0
     assert "all_reduce" in r["phases_ms"] and "cpu_baseline" not in r

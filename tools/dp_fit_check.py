@@ -10,7 +10,9 @@ in size: before round 2 the ranks ran 4 and 3 batches per epoch and the run hung
 all-reduce.  Checks, per model family (hash + tiny MLP on the bucketed all-reduce path and on the
 reduce-scatter path, SIREN on the flat all-reduce path, the BatchNorm decoder on the autograd
 path): every rank runs the same number of steps, and the replicas hold bitwise identical
-parameters after `fit`.  Rank 0 writes OUT/dp_fit.json.
+parameters after `fit`.  Then every fused gradient-exchange form (plain all-reduce, bucketed
+all-reduce, reduce-scatter) against ONE process stepping on the concatenated batch
+(`union_check`).  Rank 0 writes OUT/dp_fit.json.
 """
 import json
 import os
@@ -37,6 +39,47 @@ def build(kind):
                           lr=5e-3)  # the reference's BatchNorm + GELU decoder: autograd path
 
 
+def union_check(rank, world):
+    """Each data-parallel form of the fused step against a single process on the union batch: the mean
+    over equal-sized local means is the global mean, so the reduced gradient of the first step must
+    agree to rounding and so must the parameters after it wherever Adam is well conditioned."""
+    from mri_interpolation_amd.trainer import FusedStep
+    n, out = 4096, {}
+
+    def batch(r):
+        g = torch.Generator().manual_seed(100 + r)
+        return torch.rand(n, 3, generator=g).cuda(), torch.rand(n, 1, generator=g).cuda()
+
+    ref = build("hash").cuda()
+    one = FusedStep(ref, ref.configure_optimizers(), 1)
+    one.train_step(torch.cat([batch(r)[0] for r in range(world)]),
+                   torch.cat([batch(r)[1] for r in range(world)]))
+    torch.cuda.synchronize()
+    g_one, p_one = one.flat._grad_all.clone(), one.flat._param_all.clone()
+    for name, mode, buckets in (("all_reduce_1", "all_reduce", 1), ("all_reduce_4", "all_reduce", 4),
+                                ("reduce_scatter", "reduce_scatter", 1)):
+        net = build("hash").cuda()
+        step = FusedStep(net, net.configure_optimizers(), world)
+        step.dp_mode, step.grad_buckets = mode, buckets
+        step.train_step(*batch(rank))
+        torch.cuda.synchronize()
+        lo, hi = (0, step.flat.numel) if mode == "all_reduce" else \
+            parallel.shard_range(step.flat._grad_all.numel(), rank, world)  # the reduced part of the buffer
+        g = step.flat._grad_all[lo:hi]
+        g_err = float((g - g_one[lo:hi]).abs().max() / g_one.abs().max())
+        safe = g_one.abs() > 1e-3 * g_one.abs().max()  # |g| >> eps: Adam's step does not amplify rounding
+        p_err = float(((step.flat._param_all - p_one).abs() * safe).max() / p_one.abs().max())
+        worst = torch.tensor([g_err, p_err], dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            worst = worst.cuda()
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        out[name] = dict(grad_rel_err=float(worst[0]), param_rel_err=float(worst[1]),
+                         groups=len(step.last_group_bytes))
+        assert float(worst[0]) <= 1e-6, f"{name}: reduced gradient differs from the single process: {out[name]}"
+        assert float(worst[1]) <= 1e-5, f"{name}: parameters differ from the single process: {out[name]}"
+    return out
+
+
 def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else "."
     rank, world, local = parallel.init()
@@ -52,7 +95,8 @@ def main():
         loader = dm.train_dataloader(rank, world)
         net = build(kind).cuda()
         tr = Trainer(max_epochs=2, accumulate_grad_batches=2 if kind == "hash" else None,
-                     dp_mode="reduce_scatter" if kind == "hash_rs" else "all_reduce")
+                     dp_mode="reduce_scatter" if kind == "hash_rs" else "all_reduce",
+                     grad_buckets=4 if kind == "hash" else 1)  # "hash": the bucketed, overlapped form
         tr.fit(net, loader)
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
@@ -73,6 +117,7 @@ def main():
                                                            build(kind).cuda().parameters()])).any()))
         assert same, f"{kind}: replicas differ after fit"
         assert int(lo) == int(hi), f"{kind}: ranks ran {int(lo)}..{int(hi)} steps"
+    report["union"] = union_check(rank, world)
     parallel.barrier()
     dist.destroy_process_group()
     if rank == 0:
