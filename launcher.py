@@ -134,9 +134,12 @@ def main(argv=None):
     config.norm_siren = config.model_class in ("SirenNet", "ModulatedSirenNet")
 
     model = build_model(config, models).cuda()
-    if config.checkpoint_path:  # reference launcher.py:97-117
-        ckpt = torch.load(config.checkpoint_path, map_location="cuda", weights_only=True)
-        model.load_state_dict(ckpt.get("state_dict", ckpt))
+    if config.checkpoint_path:  # reference launcher.py:97-117 (model_cls.load_from_checkpoint)
+        from mri_interpolation_amd import checkpoint
+        # parameters AND the optimiser's moments / step count: resuming must not restart Adam's bias
+        # correction (Trainer.fit reuses model.optimizer)
+        model.optimizer = model.configure_optimizers()
+        checkpoint.load(config.checkpoint_path, model, model.optimizer, map_location="cuda")
     datamodule = datamodules.MriDataModule(config=config, volume=volume,
                                            norm_siren=config.norm_siren)
     datamodule.prepare_data()
@@ -173,12 +176,15 @@ def main(argv=None):
         config.log = str(version)
     os.makedirs(out_dir, exist_ok=True)
 
-    # Lightning's default checkpoint: lightning_logs/version_N/checkpoints/epoch=E-step=S.ckpt
+    # Lightning's default checkpoint, lightning_logs/version_N/checkpoints/epoch=E-step=S.ckpt, in the
+    # layout Lightning writes (checkpoint.py): the reference's load_from_checkpoint reads it
+    from mri_interpolation_amd import checkpoint
     os.makedirs(os.path.join(out_dir, "checkpoints"), exist_ok=True)
-    torch.save(dict(state_dict={k: v.detach().cpu() for k, v in model.state_dict().items()},
-                    epoch=config.epochs - 1, global_step=trainer.global_step),
-               os.path.join(out_dir, "checkpoints",
-                            f"epoch={config.epochs - 1}-step={trainer.global_step}.ckpt"))
+    if rank == 0:
+        checkpoint.save(os.path.join(out_dir, "checkpoints",
+                                     f"epoch={config.epochs - 1}-step={trainer.global_step}.ckpt"),
+                        model, getattr(model, "optimizer", None), epoch=config.epochs - 1,
+                        global_step=trainer.global_step)
 
     pred = torch.concat(trainer.predict(model, test_loader))
     truth = datamodule.dataset.pixels

@@ -101,9 +101,9 @@ def level_lookup(x: torch.Tensor, table: torch.Tensor, resolution: Resolution) -
     if isinstance(resolution, (int, float)):
         pos = x * resolution
     else:
-        pos = x * torch.tensor(list(resolution), dtype=torch.float32)
+        pos = x * torch.tensor(list(resolution), dtype=x.dtype)  # float32 in the reference (encoding.py:205)
     cell = pos.long()                      # truncation toward zero
-    frac = pos - cell.float().detach()
+    frac = pos - cell.to(pos.dtype).detach()  # `.float()` in the reference; float64 only as a test yardstick
     cell = cell.unsqueeze(-2)
     frac = frac.unsqueeze(-2)
     floor_side = corner_mask(dim).reshape((1,) * (x.dim() - 1) + (1 << dim, dim))

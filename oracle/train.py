@@ -83,3 +83,34 @@ def train_steps(model, batches, lr: float, opt: Optional[mlp.Adam] = None):
             p.grad = None
         losses.append(float(loss))
     return losses, opt
+
+
+def as_double(model):
+    """A float64 copy of a HashMlpModel / SirenModel: the YARDSTICK of the parity tests (the same op
+    sequence evaluated in double on the same float32 inputs), against which two float32 evaluations --
+    the HIP path's and the oracle's / the reference's -- are compared with each other."""
+    import copy
+    m = copy.copy(model)
+    if isinstance(model, HashMlpModel):
+        m.tables = [t.detach().double().clone() for t in model.tables]
+        m.mlp = [(w.detach().double().clone(), b.detach().double().clone()) for w, b in model.mlp]
+    else:
+        m.params = [(w.detach().double().clone(), None if b is None else b.detach().double().clone())
+                    for w, b in model.params]
+    return m
+
+
+def loss_and_grads_chunked(model, x: torch.Tensor, y: torch.Tensor, chunk: int):
+    """loss_and_grads over row chunks (the mean over all rows is the weighted sum of the chunks' means):
+    bounds the memory of a float64 evaluation at 2^20 rows."""
+    n = x.shape[0]
+    total, grads = 0.0, None
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        loss, _, g = loss_and_grads(model, x[lo:hi], y[lo:hi])
+        wgt = (hi - lo) / n
+        total += float(loss) * wgt
+        g = [None if t is None else t * wgt for t in g]
+        grads = g if grads is None else [a if b is None else (b if a is None else a + b)
+                                         for a, b in zip(grads, g)]
+    return total, grads

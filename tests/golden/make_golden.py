@@ -292,12 +292,82 @@ def round2_fixtures(encoding, models):
          raw_int16=np.ascontiguousarray(vol))
 
 
+def round3_fixtures(encoding, models):
+    """Fixture added in round 3 (the earlier ones stay byte-identical): O7c the reference's DEFAULT model
+    -- `config.model_cls = HashMLP`, decoder blocks Linear -> BatchNorm1d -> GELU -> Dropout(0)
+    (models.py:712-739), applied in sequence -- in train() mode: loss, EVERY gradient
+    (tables, Linear and BatchNorm weights / biases), the running statistics, and two Adam steps over
+    the parameters `configure_optimizers` hands to Adam (models.py:68-70), the dead `layers.*` stack
+    included (its gradients are None, Adam skips it: Q3)."""
+    kw = dict(n_levels=4, n_features_per_level=1, log2_hashmap_size=23,
+              base_resolution=(64, 64, 5), finest_resolution=(352, 352, 15))
+    hm = models.HashMLP(dim_in=3, dim_hidden=64, dim_out=1, n_layers=2, lr=5e-3, **kw)
+    sizes = load_tables(hm.encoder, 95, 0.5)
+    params = omlp.linear_init([4, 64, 1], 96)
+    with torch.no_grad():
+        for blk, (w, b) in zip(hm.decoder, params):
+            blk[0].weight.copy_(w)
+            blk[0].bias.copy_(b)
+            # BatchNorm affine parameters away from their (1, 0) init, so that their gradients matter
+            blk[1].weight.copy_(torch.from_numpy(detrand.uniform(blk[1].weight.numel(), 970, 0.5, 1.5)))
+            blk[1].bias.copy_(torch.from_numpy(detrand.uniform(blk[1].bias.numel(), 971, -0.2, 0.2)))
+    hm.train()
+    opt = hm.configure_optimizers()  # Adam(self.parameters(), lr) -- reference models.py:68-70
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 5e-3
+    arrays = {}
+    for step in range(2):
+        x = detrand.uniform(320 * 3, 980 + step, 0.0, 1.0).reshape(320, 3)
+        y = detrand.uniform(320, 990 + step, 0.0, 1.0).reshape(320, 1)
+        opt.zero_grad()
+        z = hm.encoder(torch.from_numpy(x))
+        for blk in hm.decoder:  # HashMLP.forward as intended (Q1)
+            z = blk(z)
+        loss = torch.nn.functional.mse_loss(torch.from_numpy(y), z)  # training_step, models.py:64
+        loss.backward()
+        arrays[f"x_{step}"], arrays[f"y_{step}"] = x, y
+        arrays[f"pred_{step}"] = z.detach().numpy().copy()
+        arrays[f"loss_{step}"] = np.float32(loss.item())
+        if step == 0:
+            idx, val = sparse_grads(hm.encoder)
+            for l, (i, v) in enumerate(zip(idx, val)):
+                arrays[f"grad_idx_{l}"], arrays[f"grad_val_{l}"] = i, v.copy()
+            for i, blk in enumerate(hm.decoder):
+                arrays[f"gw_{i}"] = blk[0].weight.grad.numpy().copy()
+                arrays[f"gb_{i}"] = blk[0].bias.grad.numpy().copy()
+                arrays[f"bn_gw_{i}"] = blk[1].weight.grad.numpy().copy()
+                arrays[f"bn_gb_{i}"] = blk[1].bias.grad.numpy().copy()
+        opt.step()
+        for i, blk in enumerate(hm.decoder):
+            arrays[f"w_{step}_{i}"] = blk[0].weight.detach().numpy().copy()
+            arrays[f"b_{step}_{i}"] = blk[0].bias.detach().numpy().copy()
+            arrays[f"bn_w_{step}_{i}"] = blk[1].weight.detach().numpy().copy()
+            arrays[f"bn_b_{step}_{i}"] = blk[1].bias.detach().numpy().copy()
+            arrays[f"bn_mean_{step}_{i}"] = blk[1].running_mean.numpy().copy()
+            arrays[f"bn_var_{step}_{i}"] = blk[1].running_var.numpy().copy()
+        for l, lvl in enumerate(hm.encoder.levels):
+            rows = arrays[f"grad_idx_{l}"]
+            arrays[f"table_{step}_{l}"] = lvl.embedding.weight.detach().numpy()[rows].copy()
+    hm.eval()  # the running statistics in use: predict_step's forward
+    z = hm.encoder(torch.from_numpy(arrays["x_0"]))
+    for blk in hm.decoder:
+        z = blk(z)
+    arrays["pred_eval_after"] = z.detach().numpy().copy()
+    res = [[float(r) for r in np.atleast_1d(np.asarray(lvl.resolution, dtype=np.float64))]
+           for lvl in hm.encoder.levels]
+    save("hashmlp_bn_adam",
+         dict(ctor=dict(dim=3, **{k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}),
+              sizes=sizes, resolutions=res, table_seed=95, table_scale=0.5, mlp_seed=96, bn_seeds=[970, 971],
+              dims=[4, 64, 1], lr=5e-3, steps=2, batch=320), **arrays)
+
+
 def main():
     torch.manual_seed(1337)
     torch.set_num_threads(4)
     encoding, models = import_reference()
     if "--extra-only" in sys.argv:  # leave the existing fixtures untouched
         return extra_models(encoding, models)
+    if "--round3-only" in sys.argv:
+        return round3_fixtures(encoding, models)
     if "--round2-only" in sys.argv:
         return round2_fixtures(encoding, models)
 
@@ -495,6 +565,7 @@ def main():
          raw_int16=np.ascontiguousarray(vol[:, :, 3, 7]))
     extra_models(encoding, models)
     round2_fixtures(encoding, models)
+    round3_fixtures(encoding, models)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,142 @@
+"""Checkpoints in Lightning's layout (mri_interpolation_amd/checkpoint.py): what the reference's
+`model_cls.load_from_checkpoint` (reference launcher.py:97-117, strict) needs to be in the file, a round trip
+of parameters, Adam moments and step count, and -- where the reference is present (the build container) --
+a strict load into the reference's own classes and optimiser."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+from mri_interpolation_amd import checkpoint, models
+
+REF = os.environ.get("MRI_REFERENCE_DIR", "/root/reference")
+
+
+def _hash():
+    torch.manual_seed(5)
+    return models.HashMLP(dim_in=3, n_levels=3, n_features_per_level=2, log2_hashmap_size=9,
+                          base_resolution=4, finest_resolution=32, dim_hidden=16, dim_out=1, n_layers=2, lr=5e-3)
+
+
+def _siren():
+    torch.manual_seed(6)
+    return models.SirenNet(dim_in=3, dim_hidden=16, dim_out=1, n_layers=3, lr=1e-4)
+
+
+def _fake_moments(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    buffers = {n for n, _ in model.named_buffers()}
+    return {k: (torch.randn(v.shape, generator=g), torch.rand(v.shape, generator=g))
+            for k, v in sd.items() if k not in buffers and v.dtype == torch.float32}
+
+
+class _CpuAdam:
+    """The attributes checkpoint.load() touches of optim.Adam, over CPU tensors (the real one is GPU-only)."""
+
+    def __init__(self, model):
+        self.betas, self.eps, self.step_count = (0.9, 0.999), 1e-8, 0
+        self.param_groups = [dict(lr=model.lr)]
+        params = list(model.parameters())
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat = type("Flat", (), dict(params=params, offsets=offsets, exp_avg=torch.zeros(total),
+                                          exp_avg_sq=torch.zeros(total)))()
+
+    def flatten(self):
+        return self.flat
+
+
+@pytest.mark.parametrize("build", [_hash, _siren])
+def test_layout_and_round_trip(tmp_path, build):
+    model = build()
+    moments = _fake_moments(model, 11)
+    ckpt = checkpoint.lightning_checkpoint(model, epoch=3, global_step=40, moments=moments, step=40)
+    # what Lightning's loader indexes unconditionally, and what Trainer.fit(ckpt_path=) restores
+    for key in ("pytorch-lightning_version", "state_dict", "optimizer_states", "lr_schedulers", "epoch", "global_step"):
+        assert key in ckpt, key
+    assert isinstance(ckpt["pytorch-lightning_version"], str) and ckpt["epoch"] == 3 and ckpt["global_step"] == 40
+    sd = ckpt["state_dict"]
+    if build is _hash:  # the reference's dead BaseMLP stack: Linear(2,128), Linear(128,1)
+        assert list(sd)[:4] == ["layers.0.weight", "layers.0.bias", "layers.2.weight", "layers.2.bias"]
+        assert sd["layers.0.weight"].shape == (128, 2) and sd["layers.2.weight"].shape == (1, 128)
+        assert "encoder.levels.2.embedding.weight" in sd and "decoder.1.1.running_var" in sd
+    opt = ckpt["optimizer_states"][0]
+    names = checkpoint._reference_parameter_names(model)
+    assert opt["param_groups"][0]["params"] == list(range(len(names)))
+    assert set(opt["state"]) == {i for i, n in enumerate(names) if not n.startswith("layers.") or build is _siren}
+    path = str(tmp_path / "epoch=3-step=40.ckpt")
+    torch.save(ckpt, path)
+    # a fresh model and optimiser resume from it: parameters, moments, step count
+    fresh = build()
+    with torch.no_grad():
+        for p in fresh.parameters():
+            p.add_(1.0)
+    adam = _CpuAdam(fresh)
+    checkpoint.load(path, fresh, adam)
+    for (k, a), (_, b) in zip(model.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert adam.step_count == 40 and adam.param_groups[0]["lr"] == model.lr
+    got = {}
+    for p, off in zip(adam.flat.params, adam.flat.offsets):
+        got[id(p)] = (adam.flat.exp_avg[off:off + p.numel()].view(p.shape), adam.flat.exp_avg_sq[off:off + p.numel()].view(p.shape))
+    for name, p in fresh.named_parameters():
+        m, v = got[id(p)]
+        if name.endswith("encoder.table"):
+            for l in range(fresh.encoder.n_levels):
+                lo, hi = fresh.encoder._row_span(l)
+                want = moments[f"encoder.levels.{l}.embedding.weight"]
+                assert torch.equal(m[lo:hi], want[0]) and torch.equal(v[lo:hi], want[1])
+        else:
+            assert torch.equal(m, moments[name][0]) and torch.equal(v, moments[name][1]), name
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "models.py")),
+                    reason="the reference repository is only present in the build container")
+@pytest.mark.parametrize("kind", ["hash", "siren"])
+def test_reference_classes_load_the_checkpoint_strictly(tmp_path, kind):
+    """The file goes through `load_state_dict(strict=True)` of the reference's own HashMLP / SirenNet (what
+    `load_from_checkpoint` does after Lightning's migration step) and its optimizer state through the
+    reference's `configure_optimizers()` Adam."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    _, ref_models = make_golden.import_reference()
+    if kind == "hash":
+        model = _hash()
+        ref = ref_models.HashMLP(dim_in=3, dim_hidden=16, dim_out=1, n_layers=2, n_levels=3, n_features_per_level=2,
+                                 log2_hashmap_size=9, base_resolution=4, finest_resolution=32, lr=5e-3)
+    else:
+        model = _siren()
+        ref = ref_models.SirenNet(dim_in=3, dim_hidden=16, dim_out=1, n_layers=3, lr=1e-4)
+    moments = _fake_moments(model, 12)
+    path = str(tmp_path / "c.ckpt")
+    torch.save(checkpoint.lightning_checkpoint(model, epoch=0, global_step=9, moments=moments, step=9), path)
+    ckpt = torch.load(path, weights_only=True)
+    result = ref.load_state_dict(ckpt["state_dict"], strict=True)
+    assert not result.missing_keys and not result.unexpected_keys
+    x = torch.rand(7, 3)
+    if kind == "siren":
+        model.cpu()
+        with torch.no_grad():  # same parameters: the reference's forward on them is the oracle's
+            from oracle import mlp as omlp
+            params = [(l.weight, l.bias) for l in list(ref.layers) + [ref.last_layer]]
+            want = omlp.siren_forward(x, [(w.detach(), b.detach()) for w, b in params])
+            assert torch.allclose(ref(x), want, atol=1e-6)
+    opt = ref.configure_optimizers()
+    opt.load_state_dict(ckpt["optimizer_states"][0])
+    ref_params = list(ref.parameters())
+    names = [n for n, _ in ref.named_parameters()]
+    assert names == checkpoint._reference_parameter_names(model)
+    for i, p in enumerate(ref_params):
+        st = opt.state.get(p)
+        if names[i].startswith("layers.") and kind == "hash":
+            assert not st  # the dead stack never had a gradient
+            continue
+        assert st["exp_avg"].shape == p.shape and float(st["step"]) == 9.0
+        assert torch.equal(st["exp_avg"], moments[names[i]][0])

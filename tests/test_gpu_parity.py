@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import REL_TOL, assert_close, load_golden
+from yardstick import assert_no_worse
 from oracle import data as odata
 from oracle import detrand
 from oracle import hashgrid as ohash
@@ -585,20 +586,25 @@ def test_full_size_cfg4_step_matches_oracle(amd):
     for i, (blk, (w64, b64)) in enumerate(zip(net.decoder, params64)):
         assert_close(blk[0].weight.grad.cpu().numpy(), w64.grad.float().numpy(), REL_TOL, f"gw{i}")
         assert_close(blk[0].bias.grad.cpu().numpy(), b64.grad.float().numpy(), REL_TOL, f"gb{i}")
-        assert_close(grads[16 + 2 * i].numpy(), w64.grad.float().numpy(), 5e-5, f"oracle gw{i}")
+        # (the f32 oracle itself is further from float64 than the kernel on these sums)
+        assert_no_worse(blk[0].weight.grad.cpu().numpy(), grads[16 + 2 * i].numpy(), w64.grad.numpy(), f"gw{i}")
     # and the parameters after the optimiser step
+    model64 = otrain.as_double(model)  # float64 yardstick, copied BEFORE the f32 oracle steps
     got_loss = float(step.train_step(x.cuda(), y.cuda()))
     losses, _ = otrain.train_steps(model, [(x, y)], lr)
+    otrain.train_steps(model64, [(x.double(), y.double())], lr)
     assert abs(got_loss - float(losses[0])) <= REL_TOL * float(losses[0])
     # Adam's first step is lr * g / (|g| + eps): where the contributions to a slot nearly cancel
-    # (|g| ~ eps) it amplifies the f32 summation-order noise of EITHER implementation, so the
-    # updated tables are compared at 1e-4 of their range (the gradients above at 1e-5)
-    for level in (0, 4, 9, 15):
+    # (|g| ~ eps) it amplifies the f32 summation-order noise of EITHER implementation, so two correct
+    # f32 evaluations sit up to ~1e-4 of the range apart.  The claim tested: measured against the SAME
+    # step in float64, the kernel's parameters are no further away than the f32 oracle's (yardstick.py)
+    for level in range(16):
         lo, hi = net.encoder._row_span(level)
-        assert_close(net.encoder.table.data[lo:hi].cpu().numpy(), model.tables[level].numpy(),
-                     1e-4, f"table level {level} after Adam")
-    for blk, (w, b) in zip(net.decoder, model.mlp):
-        assert_close(blk[0].weight.data.cpu().numpy(), w.numpy(), 1e-4, "decoder weight")
+        assert_no_worse(net.encoder.table.data[lo:hi].cpu().numpy(), model.tables[level].numpy(),
+                        model64.tables[level].numpy(), f"table level {level} after Adam")
+    for blk, (w, b), (w64, b64) in zip(net.decoder, model.mlp, model64.mlp):
+        assert_no_worse(blk[0].weight.data.cpu().numpy(), w.numpy(), w64.numpy(), "decoder weight after Adam")
+        assert_no_worse(blk[0].bias.data.cpu().numpy(), b.numpy(), b64.numpy(), "decoder bias after Adam")
 
 
 def test_full_size_siren_step_decreases_loss(amd):

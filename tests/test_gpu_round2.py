@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from conftest import REL_TOL, assert_close, load_golden
+from yardstick import assert_no_worse
 from oracle import data as odata
 from oracle import detrand
 from oracle import hashgrid as ohash
@@ -194,12 +195,16 @@ def test_full_size_cfg3_siren_intensities_and_step(amd):
     want_loss, want_pred, grads = otrain.loss_and_grads(model, x, y)
     assert abs(float(step.loss) - float(want_loss)) <= REL_TOL * float(want_loss)
     assert_close(pred.cpu().numpy(), want_pred.numpy(), REL_TOL, "all 2^20 intensities")
-    # gradients are sums of 2^20 terms: f32 summation order limits agreement to ~1e-4 where
-    # terms cancel; 5e-5 of the tensor's maximum holds for every layer (measured 1e-6 .. 2e-5)
+    # gradients are sums of 2^20 terms: two f32 summation orders differ by up to ~1e-4 where terms
+    # cancel.  Yardstick: the same step in float64 (chunked, same f32 inputs); the kernel must be no
+    # further from it than the f32 oracle is
+    loss64, grads64 = otrain.loss_and_grads_chunked(otrain.as_double(model), x.double(), y.double(), 1 << 16)
+    assert abs(float(step.loss) - loss64) <= 2.0 * abs(float(want_loss) - loss64) + 1e-6 * loss64
     layers = list(net.layers) + [net.last_layer]
     for i, layer in enumerate(layers):
-        assert_close(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), 5e-5, f"gw{i}")
-        assert_close(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), 5e-5, f"gb{i}")
+        assert_no_worse(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), grads64[2 * i].numpy(), f"gw{i}")
+        assert_no_worse(layer.bias.grad.cpu().numpy(), grads[2 * i + 1].numpy(), grads64[2 * i + 1].numpy(),
+                        f"gb{i}")
 
 
 # ------------------------------------------------------------------ gradient w.r.t. coordinates
@@ -385,6 +390,8 @@ def test_siren_chain_e2e_adam_golden(amd):
     fx = load_golden("e2e_siren256_adam")
     m = fx.meta
     net = _load_siren(amd, m)
+    model64 = otrain.as_double(otrain.SirenModel(m["dim_in"], m["dim_hidden"], 1, m["n_layers"], seed=m["seed"]))
+    opt64 = omlp.Adam(model64.parameters(), lr=m.get("lr", 1e-4))
     step = amd.trainer.FusedStep(net, net.configure_optimizers())
     assert step.use_chain
     layers = list(net.layers) + [net.last_layer]
@@ -403,18 +410,21 @@ def test_siren_chain_e2e_adam_golden(amd):
                 assert_close(layer.weight.grad.cpu().numpy()[:head.shape[0]], head, REL_TOL, f"gw{i}")
         loss = float(step.train_step(x, y))
         assert abs(loss - float(fx[f"loss_{s}"])) <= REL_TOL * abs(float(fx[f"loss_{s}"]))
+        # float64 yardstick: the oracle's SirenNet in double, same batches, same Adam
+        otrain.train_steps(model64, [(x.double().cpu(), y.double().cpu())], m.get("lr", 1e-4), opt64)
         for i, layer in enumerate(layers):
-            # Gradients (above) agree to 1e-5.  Adam's first steps are lr g / (|g| + eps): an
-            # element whose gradient is ~eps = 1e-8 turns a 1e-9 difference of g into 0.1 lr =
-            # 1e-5 of weight, i.e. 6e-5 of max |w| = 0.15 -- for either of two correct f32
-            # evaluations.  As in test_full_size_cfg4_step_matches_oracle: 1e-4 after Adam, and
-            # the norm (which such isolated elements do not move) at 1e-5.
+            # Gradients (above) agree to 1e-5.  Adam's first steps are lr g / (|g| + eps): an element whose
+            # gradient is ~eps = 1e-8 turns a 1e-9 difference of g into 0.1 lr = 1e-5 of weight, i.e. 6e-5
+            # of max |w| = 0.15 -- for either of two correct f32 evaluations.  So: the kernel's weights
+            # against the REFERENCE's (the fixture), both measured from the float64 run; and the norm
+            # (which such isolated elements do not move) at 1e-5.
             w = layer.weight.detach().cpu().numpy()
             head = fx[f"w_{s}_{i}"]
-            assert_close(w[:head.shape[0]], head, 1e-4, f"w{i} step {s}")
+            w64, b64 = model64.params[i]
+            assert_no_worse(w[:head.shape[0]], head, w64.numpy()[:head.shape[0]], f"w{i} step {s}")
             assert abs(np.linalg.norm(w.astype(np.float64)) - float(fx[f"wnorm_{s}_{i}"])) \
                 <= REL_TOL * float(fx[f"wnorm_{s}_{i}"])
-            assert_close(layer.bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], 1e-4, f"b{i} step {s}")
+            assert_no_worse(layer.bias.detach().cpu().numpy(), fx[f"b_{s}_{i}"], b64.numpy(), f"b{i} step {s}")
 
 
 @pytest.mark.parametrize("hidden,dim_in,n_layers", [(256, 3, 5), (256, 2, 2), (256, 4, 1), (256, 1, 8),
@@ -645,12 +655,24 @@ def test_gradient_accumulation_equals_one_step_on_the_union(amd, kind):
         lo = 0.0
     else:
         net, lo = amd.models.SirenNet(3, 64, 1, 3, lr=1e-4), -1.0
+    # float64 yardstick of the union-batch steps: the oracle's model with this net's parameters, in double
+    if kind == "hash_tiny":
+        model64 = otrain.HashMlpModel(3, 8, 2, 14, 8, 64, [64, 64])
+        model64.tables = [net.encoder.table.data[a:b].clone()
+                          for a, b in (net.encoder._row_span(l) for l in range(8))]
+        model64.mlp = [(blk[0].weight.data.clone(), blk[0].bias.data.clone()) for blk in net.decoder]
+    else:
+        model64 = otrain.SirenModel(3, 64, 1, 3)
+        model64.params = [(l.weight.data.clone(), l.bias.data.clone()) for l in list(net.layers) + [net.last_layer]]
+    model64 = otrain.as_double(model64)
+    opt64 = omlp.Adam(model64.parameters(), lr=5e-3 if kind == "hash_tiny" else 1e-4)
     nets = [net.cuda(), copy.deepcopy(net).cuda()]
     steps = [amd.trainer.FusedStep(m, m.configure_optimizers()) for m in nets]
     n = 6000
     x = torch.rand(2 * n, 3, device="cuda") * (1 - lo) + lo
     y = torch.rand(2 * n, 1, device="cuda")
     for _ in range(2):
+        otrain.train_steps(model64, [(x.double().cpu(), y.double().cpu())], opt64.lr, opt64)
         steps[0].train_step(x, y)
         l1 = float(steps[1].train_step(x[:n], y[:n], first=True, step=False, divisor=2.0))
         count = steps[1].opt.step_count
@@ -659,8 +681,16 @@ def test_gradient_accumulation_equals_one_step_on_the_union(amd, kind):
         assert abs(0.5 * (l1 + l2) - float(steps[0].loss)) <= 1e-5 * float(steps[0].loss)
         assert_close(steps[1].flat.grad.cpu().numpy(), steps[0].flat.grad.cpu().numpy(), REL_TOL,
                      "accumulated gradient")
-    assert_close(steps[1].flat.param.cpu().numpy(), steps[0].flat.param.cpu().numpy(), 1e-4,
-                 "parameters after two accumulated steps")
+    # after two Adam steps the two f32 evaluations (one launch / two accumulated halves) may sit apart
+    # where |g| ~ eps; measured from the float64 run of the same two steps, the accumulated form must be
+    # no further away than the one-launch form, tensor by tensor
+    want64 = model64.parameters()
+    if kind == "hash_tiny":  # the module holds ONE table parameter, the oracle one per level
+        want64 = [torch.cat(want64[:8])] + want64[8:]
+    assert len(want64) == len(list(nets[0].parameters()))
+    for p_acc, p_one, p64 in zip(nets[1].parameters(), nets[0].parameters(), want64):
+        assert_no_worse(p_acc.detach().cpu().numpy().reshape(-1), p_one.detach().cpu().numpy().reshape(-1),
+                        p64.numpy().reshape(-1), "parameters after two accumulated steps")
 
 
 def test_trainer_accumulates(amd):

@@ -198,3 +198,134 @@ def test_packed_records_over_200_steps(amd):
     print(f"200 steps: PSNR f32 records {db_f32:.4f} dB, packed {db_pack:.4f} dB; "
           f"parameters differ by {rel_max:.3e} of max, {rel_l2:.3e} in L2")
     assert abs(db_pack - db_f32) <= 0.01, (db_f32, db_pack)
+
+
+# --------------------------------------------------------------------------- the reference's default model
+def test_hashmlp_batchnorm_decoder_gradients_and_adam(amd):
+    """`config.model_cls = HashMLP` as the reference builds it (models.py:712-739): encoder + Linear ->
+    BatchNorm1d -> GELU -> Dropout(0) blocks in train() mode through the module / autograd path -- the HIP
+    encoder and Linear kernels under torch's BatchNorm -- against the reference: loss, every gradient
+    (tables, Linear and BatchNorm parameters), running statistics, two Adam steps."""
+    fx = load_golden("hashmlp_bn_adam")
+    m, c = fx.meta, fx.meta["ctor"]
+    net = amd.models.HashMLP(dim_in=3, n_levels=c["n_levels"], n_features_per_level=c["n_features_per_level"],
+                             log2_hashmap_size=c["log2_hashmap_size"],
+                             base_resolution=tuple(c["base_resolution"]),
+                             finest_resolution=tuple(c["finest_resolution"]), dim_hidden=64, dim_out=1,
+                             n_layers=2, lr=m["lr"])
+    assert net.encoder.sizes == m["sizes"] and isinstance(net.decoder[0][1], torch.nn.BatchNorm1d)
+    with torch.no_grad():
+        net.encoder.table.copy_(torch.cat(ohash.init_tables(m["sizes"], 1, m["table_seed"], m["table_scale"])))
+        for blk, (w, b) in zip(net.decoder, omlp.linear_init(m["dims"], m["mlp_seed"])):
+            blk[0].weight.copy_(w)
+            blk[0].bias.copy_(b)
+            blk[1].weight.copy_(torch.from_numpy(detrand.uniform(blk[1].weight.numel(), m["bn_seeds"][0], 0.5, 1.5)))
+            blk[1].bias.copy_(torch.from_numpy(detrand.uniform(blk[1].bias.numel(), m["bn_seeds"][1], -0.2, 0.2)))
+    net.cuda().train()
+    opt = net.configure_optimizers()
+    b_first = [blk[0].bias.detach().cpu().numpy().copy() for blk in net.decoder]
+    for step in range(m["steps"]):
+        x = torch.as_tensor(fx[f"x_{step}"]).cuda()
+        y = torch.as_tensor(fx[f"y_{step}"]).cuda()
+        b_before = [blk[0].bias.detach().cpu().numpy().copy() for blk in net.decoder]
+        opt.zero_grad()
+        loss = net.training_step((x, y), step)
+        loss.backward()
+        assert abs(float(loss) - float(fx[f"loss_{step}"])) <= REL_TOL * float(fx[f"loss_{step}"])
+        if step == 0:
+            g = net.encoder.table.grad.cpu().numpy()
+            for l in range(net.encoder.n_levels):
+                lo, hi = net.encoder._row_span(l)
+                want = np.zeros((hi - lo, 1), dtype=np.float32)
+                want[fx[f"grad_idx_{l}"]] = fx[f"grad_val_{l}"]
+                assert set(np.nonzero(g[lo:hi, 0])[0]) <= set(fx[f"grad_idx_{l}"].tolist()), f"level {l}: stray slot"
+                assert_close(g[lo:hi], want, REL_TOL, f"table gradient level {l}")
+            for i, blk in enumerate(net.decoder):
+                assert_close(blk[0].weight.grad.cpu().numpy(), fx[f"gw_{i}"], REL_TOL, f"gw{i}")
+                assert_close(blk[1].weight.grad.cpu().numpy(), fx[f"bn_gw_{i}"], REL_TOL, f"bn gw{i}")
+                assert_close(blk[1].bias.grad.cpu().numpy(), fx[f"bn_gb_{i}"], REL_TOL, f"bn gb{i}")
+                # the Linear bias in front of a train-mode BatchNorm: exactly zero in exact arithmetic,
+                # rounding noise in any f32 evaluation (tests/test_oracle_golden.py says what follows from it)
+                assert float(blk[0].bias.grad.abs().max()) <= 1e-5 * float(blk[0].weight.grad.abs().max())
+        opt.step()
+        for i, blk in enumerate(net.decoder):
+            assert_close(blk[0].weight.detach().cpu().numpy(), fx[f"w_{step}_{i}"], REL_TOL,
+                         f"w{i} step {step}")
+            assert_close(blk[1].weight.detach().cpu().numpy(), fx[f"bn_w_{step}_{i}"], REL_TOL, f"bn w{i} step {step}")
+            assert_close(blk[1].bias.detach().cpu().numpy(), fx[f"bn_b_{step}_{i}"], REL_TOL, f"bn b{i} step {step}")
+            b_ref = fx[f"b_{step - 1}_{i}"] if step else b_first[i]
+            own = blk[1].running_mean.cpu().numpy() - 0.1 * b_before[i]
+            ref = fx[f"bn_mean_{step}_{i}"] - 0.1 * b_ref
+            assert np.abs(own - ref).max() <= REL_TOL * np.abs(fx[f"bn_mean_{step}_{i}"]).max(), (i, step)
+            assert_close(blk[1].running_var.cpu().numpy(), fx[f"bn_var_{step}_{i}"], REL_TOL, f"bn var{i} step {step}")
+        table = net.encoder.table.detach().cpu().numpy()
+        for l in range(net.encoder.n_levels):
+            lo, hi = net.encoder._row_span(l)
+            assert_close(table[lo:hi][fx[f"grad_idx_{l}"]], fx[f"table_{step}_{l}"], REL_TOL, f"table {l} step {step}")
+    # eval mode from the reference's final state (the rows x_0 touches are in the fixture)
+    last = m["steps"] - 1
+    with torch.no_grad():
+        for l in range(net.encoder.n_levels):
+            lo, hi = net.encoder._row_span(l)
+            net.encoder.table.data[lo:hi][torch.as_tensor(fx[f"grad_idx_{l}"].astype(np.int64)).cuda()] = \
+                torch.as_tensor(fx[f"table_{last}_{l}"]).cuda()
+        for i, blk in enumerate(net.decoder):
+            blk[0].weight.copy_(torch.as_tensor(fx[f"w_{last}_{i}"]))
+            blk[0].bias.copy_(torch.as_tensor(fx[f"b_{last}_{i}"]))
+            blk[1].weight.copy_(torch.as_tensor(fx[f"bn_w_{last}_{i}"]))
+            blk[1].bias.copy_(torch.as_tensor(fx[f"bn_b_{last}_{i}"]))
+            blk[1].running_mean.copy_(torch.as_tensor(fx[f"bn_mean_{last}_{i}"]))
+            blk[1].running_var.copy_(torch.as_tensor(fx[f"bn_var_{last}_{i}"]))
+        net.eval()
+        pred = net.predict_step((torch.as_tensor(fx["x_0"]).cuda(), None), 0)
+    assert_close(pred.cpu().numpy(), fx["pred_eval_after"], REL_TOL, "eval-mode prediction")
+
+
+# --------------------------------------------------------------------------- checkpoints
+def test_launcher_checkpoint_resumes_parameters_and_optimizer(amd, tmp_path):
+    """`launcher.py` writes Lightning's default checkpoint in Lightning's layout (checkpoint.py); loaded
+    into a fresh model + optimiser it restores parameters, BOTH Adam moments and the step count bit for
+    bit, and `--checkpoint_path` continues training from it (reference launcher.py:97-117)."""
+    import glob
+    import launcher
+    from mri_interpolation_amd import checkpoint
+    out = str(tmp_path / "run")
+    argv = ["--model_class", "HashMLP", "--tiny_mlp", "--synthetic", "24,24,24", "--batch_size", "2048",
+            "--epochs", "2", "--out_dir", out, "--log_every", "0"]
+    launcher.main(argv)
+    files = glob.glob(os.path.join(out, "checkpoints", "epoch=1-step=*.ckpt"))
+    assert len(files) == 1
+    ckpt = torch.load(files[0], weights_only=True)
+    steps = ckpt["global_step"]
+    assert steps >= 2 and ckpt["epoch"] == 1 and ckpt["pytorch-lightning_version"]
+    assert any(k.startswith("layers.") for k in ckpt["state_dict"])  # the reference's dead stack (Q3)
+    state = ckpt["optimizer_states"][0]["state"]
+    assert state and all(float(s["step"]) == steps for s in state.values())
+    # a fresh model with the same constructor arguments
+    sd = ckpt["state_dict"]
+    n_levels = len([k for k in sd if k.startswith("encoder.levels.")])
+    hidden, k_in = sd["decoder.0.0.weight"].shape
+    net = amd.models.HashMLP(3, n_levels, k_in // n_levels, 19, 16, FIN4, dim_hidden=hidden, n_layers=3,
+                             activation=torch.nn.ReLU, batch_norm=False, final_activation=False, lr=5e-3)
+    if [tuple(sd[f"encoder.levels.{l}.embedding.weight"].shape) for l in range(n_levels)] != \
+            [(s, k_in // n_levels) for s in net.encoder.sizes]:
+        pytest.skip("the launcher's default --tiny_mlp encoder is not the one rebuilt here")
+    net.cuda()
+    opt = net.configure_optimizers()
+    checkpoint.load(files[0], net, opt, map_location="cuda")
+    assert opt.step_count == steps
+    again = checkpoint.lightning_checkpoint(net, opt, epoch=1, global_step=steps)
+    for k, v in ckpt["state_dict"].items():
+        if not k.startswith("layers."):
+            assert torch.equal(v, again["state_dict"][k]), k
+    for i, s in state.items():
+        t = again["optimizer_states"][0]["state"][i]
+        assert torch.equal(s["exp_avg"], t["exp_avg"]) and torch.equal(s["exp_avg_sq"], t["exp_avg_sq"]), i
+    # and the launcher resumes from it: the first logged loss of the resumed run continues the curve
+    out2 = str(tmp_path / "resumed")
+    launcher.main(argv[:-4] + ["--out_dir", out2, "--log_every", "0", "--checkpoint_path", files[0]])
+    resumed = glob.glob(os.path.join(out2, "checkpoints", "*.ckpt"))
+    assert len(resumed) == 1
+    r = torch.load(resumed[0], weights_only=True)
+    rs = r["optimizer_states"][0]["state"]
+    assert all(float(s["step"]) == 2 * steps for s in rs.values()), "the optimiser's step count restarted"

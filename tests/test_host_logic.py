@@ -265,3 +265,29 @@ def test_entry_points_set_the_ipc_mode_before_torch_loads():
                 assert seen_env or not any(m.split(".")[0] in ("torch", "mri_interpolation_amd")
                                            for m in mods), f"{name}: torch imported before the default"
         assert seen_env, name
+
+
+@pytest.mark.parametrize("frames", [15, 14])
+def test_interp_baseline_equals_scipy_linear_interpolation(frames):
+    """interp.py's counterpart (reference interp.py:35-50: even frames -> itk.LinearInterpolateImageFunction,
+    evaluated at (t / 2, y, x) for every voxel) against an INDEPENDENT implementation of the same linear
+    interpolation, `scipy.ndimage.map_coordinates(order=1)` (ITK itself is not installed), on
+    the reference's own slice [:, :, 3, :] of the sample volume, for an odd and an even number of frames (an
+    even one puts the last odd frame half a step beyond the last even frame: ITK clamps the upper
+    neighbour to the buffer's end, `mode="nearest"` does the same)."""
+    import interp
+    from scipy import ndimage
+    fx = load_golden("sample_volume")
+    vol = fx["raw_int16"][:, :, 3, :frames].astype(np.float32) * np.float32(fx.meta["scl_slope"])
+    data = vol / vol.max()                                        # interp.py:26-27
+    values = data[..., ::2].astype(np.float64)                    # interp.py:35
+    ix, iy, it = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in data.shape], indexing="ij")
+    want = ndimage.map_coordinates(values, [ix, iy, it / 2.0], order=1, mode="nearest")
+    got = interp.interpolate_even_frames(data)
+    assert got.shape == data.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-12
+    assert np.array_equal(got[..., ::2], values)                  # the trained frames are reproduced exactly
+    # and the PSNR figure bench.py reports beside the network's (held-out odd frames)
+    odd = slice(1, None, 2)
+    mse = np.mean((got[..., odd] - data[..., odd].astype(np.float64)) ** 2)
+    assert abs(interp.psnr(got[..., odd], data[..., odd]) - 10.0 * np.log10(1.0 / mse)) <= 1e-9

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from conftest import assert_close, load_golden
+from oracle import detrand
 from oracle import data as odata
 from oracle import hashgrid as ohash
 from oracle import mlp as omlp
@@ -282,6 +283,93 @@ def test_hashmlp_gelu_notebook_decoder():
         for l, t in enumerate(tables):
             assert_close(t.numpy()[fx[f"grad_idx_{l}"]], fx[f"table_{step}_{l}"], 1e-6,
                          f"table {l} step {step}")
+
+
+def _bn_state(m, dims):
+    """BatchNorm1d members of the reference's decoder blocks as the fixture initialised them."""
+    out = []
+    for fan_out in dims[1:]:
+        out.append(dict(weight=torch.from_numpy(detrand.uniform(fan_out, m["bn_seeds"][0], 0.5, 1.5).copy()),
+                        bias=torch.from_numpy(detrand.uniform(fan_out, m["bn_seeds"][1], -0.2, 0.2).copy()),
+                        running_mean=torch.zeros(fan_out), running_var=torch.ones(fan_out)))
+    return out
+
+
+def test_hashmlp_batchnorm_decoder_gradients_and_adam():
+    """The reference's DEFAULT model (config.model_cls = HashMLP): encoder + Linear -> BatchNorm1d -> GELU
+    -> Dropout(0) blocks in train() mode (models.py:712-739, in sequence per SURVEY Q1) -- forward, loss,
+    every gradient incl. BatchNorm weight / bias, the running statistics, two Adam steps, and the
+    eval-mode prediction with the statistics those steps left: against the reference modules' outputs."""
+    fx = load_golden("hashmlp_bn_adam")
+    m, c = fx.meta, fx.meta["ctor"]
+    res, sizes = ohash.resolutions_for(c["dim"], c["n_levels"], c["log2_hashmap_size"],
+                                       tuple(c["base_resolution"]), tuple(c["finest_resolution"]))
+    assert sizes == m["sizes"]
+    tables = ohash.init_tables(sizes, c["n_features_per_level"], m["table_seed"], m["table_scale"])
+    params = omlp.linear_init(m["dims"], m["mlp_seed"])
+    bn = _bn_state(m, m["dims"])
+    flat = list(tables) + [t for wb in params for t in wb] + [s[k] for s in bn for k in ("weight", "bias")]
+    opt = omlp.Adam(flat, lr=m["lr"])
+    for step in range(m["steps"]):
+        for p in flat:
+            p.requires_grad_(True)
+            p.grad = None
+        b_before = [b.detach().numpy().copy() for _, b in params]  # the biases this step's batch means hold
+        z = ohash.encode(torch.from_numpy(fx[f"x_{step}"]), tables, res)
+        pred = omlp.hashmlp_decoder_forward(z, params, bn, training=True)
+        loss = omlp.mse_loss(pred, torch.from_numpy(fx[f"y_{step}"]))
+        loss.backward()
+        assert_close(pred.detach().numpy(), fx[f"pred_{step}"], 1e-6, f"pred step {step}")
+        assert abs(float(loss.detach()) - float(fx[f"loss_{step}"])) <= 1e-6 * float(fx[f"loss_{step}"])
+        if step == 0:
+            for l, t in enumerate(tables):
+                nz = torch.nonzero(t.grad.abs().sum(dim=1) != 0).flatten().numpy()
+                np.testing.assert_array_equal(nz, fx[f"grad_idx_{l}"])
+                assert_close(t.grad[nz].numpy(), fx[f"grad_val_{l}"], 2e-6, f"table grad {l}")
+            for i, ((w, b), s) in enumerate(zip(params, bn)):
+                assert_close(w.grad.numpy(), fx[f"gw_{i}"], 2e-6, f"gw{i}")
+                assert_close(s["weight"].grad.numpy(), fx[f"bn_gw_{i}"], 2e-6, f"bn gw{i}")
+                assert_close(s["bias"].grad.numpy(), fx[f"bn_gb_{i}"], 2e-6, f"bn gb{i}")
+                # a Linear bias in front of a train-mode BatchNorm has an exactly-zero gradient in exact
+                # arithmetic (the batch mean absorbs it): what both sides hold is rounding noise, which
+                # Adam then turns into steps of ~lr in a direction no two evaluations share -- with no
+                # effect on any output (the next batch mean absorbs the bias again).  Hence no assert on
+                # the Linear biases after Adam, here or in the GPU test.
+                assert np.abs(fx[f"gb_{i}"]).max() <= 1e-5 * np.abs(fx[f"gw_{i}"]).max()
+                assert float(b.grad.abs().max()) <= 1e-5 * float(w.grad.abs().max())
+        grads = [p.grad for p in flat]
+        for p in flat:
+            p.requires_grad_(False)
+        opt.step(grads)
+        for i, ((w, b), s) in enumerate(zip(params, bn)):
+            assert_close(w.numpy(), fx[f"w_{step}_{i}"], 1e-5, f"w{i} step {step}")
+            assert_close(s["weight"].numpy(), fx[f"bn_w_{step}_{i}"], 1e-6, f"bn w{i} step {step}")
+            assert_close(s["bias"].numpy(), fx[f"bn_b_{step}_{i}"], 1e-6, f"bn b{i} step {step}")
+            # running mean = momentum-weighted batch means of W z + b: b's noise-driven Adam steps (see
+            # above) enter it from the second step on, so compare it with this side's own bias taken out
+            b_ref = fx[f"b_{step - 1}_{i}"] if step else omlp.linear_init(m["dims"], m["mlp_seed"])[i][1].numpy()
+            b_own = b_before[i]
+            own = s["running_mean"].numpy() - 0.1 * b_own
+            ref = fx[f"bn_mean_{step}_{i}"] - 0.1 * b_ref
+            assert np.abs(own - ref).max() <= 1e-5 * np.abs(fx[f"bn_mean_{step}_{i}"]).max(), \
+                f"bn mean{i} step {step}: {np.abs(own - ref).max():.3e}"
+            assert_close(s["running_var"].numpy(), fx[f"bn_var_{step}_{i}"], 1e-5, f"bn var{i} step {step}")
+        for l, t in enumerate(tables):
+            assert_close(t.numpy()[fx[f"grad_idx_{l}"]], fx[f"table_{step}_{l}"], 1e-5,
+                         f"table {l} step {step}")
+    # eval mode (predict_step's forward) from the REFERENCE's final state -- every tensor it needs for
+    # x_0 is in the fixture (the table rows x_0 touches are the rows of grad_idx_*)
+    last = m["steps"] - 1
+    for l, t in enumerate(tables):
+        t[torch.from_numpy(fx[f"grad_idx_{l}"].astype(np.int64))] = torch.from_numpy(fx[f"table_{last}_{l}"])
+    params = [(torch.from_numpy(fx[f"w_{last}_{i}"]), torch.from_numpy(fx[f"b_{last}_{i}"]))
+              for i in range(len(params))]
+    bn = [dict(weight=torch.from_numpy(fx[f"bn_w_{last}_{i}"]), bias=torch.from_numpy(fx[f"bn_b_{last}_{i}"]),
+               running_mean=torch.from_numpy(fx[f"bn_mean_{last}_{i}"]),
+               running_var=torch.from_numpy(fx[f"bn_var_{last}_{i}"])) for i in range(len(bn))]
+    z = ohash.encode(torch.from_numpy(fx["x_0"]), tables, res)
+    pred = omlp.hashmlp_decoder_forward(z, params, bn, training=False)
+    assert_close(pred.numpy(), fx["pred_eval_after"], 1e-6, "eval-mode prediction from the reference's final state")
 
 
 def test_sample_volume_dataset_4d():
