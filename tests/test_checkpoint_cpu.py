@@ -104,9 +104,25 @@ def test_reference_classes_load_the_checkpoint_strictly(tmp_path, kind):
     """The file goes through `load_state_dict(strict=True)` of the reference's own HashMLP / SirenNet (what
     `load_from_checkpoint` does after Lightning's migration step) and its optimizer state through the
     reference's `configure_optimizers()` Adam."""
+    # the reference's modules (`encoding`, `models`, its stand-ins) and its directory on sys.path must not
+    # outlive this test: later tests import this repository's `launcher`, `interp`, ...
+    saved_path, saved_modules = list(sys.path), set(sys.modules)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import make_golden
-    _, ref_models = make_golden.import_reference()
+    try:
+        import make_golden
+        _, ref_models = make_golden.import_reference()
+        _check_reference_load(tmp_path, kind, ref_models)
+    finally:
+        sys.path[:] = saved_path
+        for name in set(sys.modules) - saved_modules:
+            mod = sys.modules[name]
+            from_ref = str(getattr(mod, "__file__", "") or "").startswith(REF)
+            stand_in = name.split(".")[0] in ("pytorch_lightning", "utils", "commentjson", "rff", "make_golden")
+            if from_ref or stand_in:
+                del sys.modules[name]
+
+
+def _check_reference_load(tmp_path, kind, ref_models):
     if kind == "hash":
         model = _hash()
         ref = ref_models.HashMLP(dim_in=3, dim_hidden=16, dim_out=1, n_layers=2, n_levels=3, n_features_per_level=2,
