@@ -152,15 +152,19 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(
   const float* __restrict__ rows = table + tab.offset[level] * 2;
   const Cell<D> c = locate<D>(x, live ? i : n - 1, tab.res[level]);
   float p0 = 0.0f, p1 = 0.0f;
+  // (cache-policy bits on these gathers -- sc0, sc1, sc0 sc1 through inline-asm loads -- measured no
+  // change, 0.108 ms in every form on one box; nt: 0.303)
+  {
 #pragma unroll
-  for (int nb = 0; nb < (1 << (D - 1)); ++nb) {
-    uint32_t h;
-    float w;
-    corner<D>(c, (nb << 1) | xc, h, w);
-    const float2 v = *reinterpret_cast<const float2*>(
-        rows + (uint64_t)slot_of(h, size, magic, pow2) * 2);
-    p0 = p0 + v.x * w;
-    p1 = p1 + v.y * w;
+    for (int nb = 0; nb < (1 << (D - 1)); ++nb) {
+      uint32_t h;
+      float w;
+      corner<D>(c, (nb << 1) | xc, h, w);
+      const float2 v = *reinterpret_cast<const float2*>(
+          rows + (uint64_t)slot_of(h, size, magic, pow2) * 2);
+      p0 = p0 + v.x * w;
+      p1 = p1 + v.y * w;
+    }
   }
   const float mine = xc ? p1 : p0, send = xc ? p0 : p1;
   const float total = mine + __shfl_xor(send, 1, 64);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Copy what tools/gpu_final.sh left under gpurun_out/r2/final (and the rocprofv3 counter CSVs under
-gpurun_out/r2/pmc_*) into the committed summaries under profiles/ and refresh profiles/traffic.json.
+"""Copy what tools/gpu_final.sh left under gpurun_out/<round>/final (and the rocprofv3 counter CSVs under
+gpurun_out/<round>/pmc_*) into the committed summaries under profiles/ and refresh profiles/traffic.json.
 
-    python tools/collect_final.py [round-tag, default r02]
+    python tools/collect_final.py [round-tag, default r03] [round-dir, default r3]
 """
 import ast
 import csv
@@ -15,8 +15,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "gpurun_out", "r2", "final")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rdir = sys.argv[2] if len(sys.argv) > 2 else "r3"
+src = os.path.join(ROOT, "gpurun_out", rdir, "final")
 dst = os.path.join(ROOT, "profiles")
 
 
@@ -28,18 +29,21 @@ for w in ("cfg2", "cfg3", "cfg4", "cfg5"):
     open(os.path.join(dst, f"{tag}_bench_{w}.json"), "w").write(last_line(os.path.join(src, f"bench_{w}.json")) + "\n")
 for w in ("cfg3", "cfg4", "cfg5"):
     open(os.path.join(dst, f"{tag}_predict_{w}.json"), "w").write(last_line(os.path.join(src, f"predict_{w}.json")) + "\n")
-for w in ("cfg3", "cfg4", "cfg5", "cfg4_predict"):
+for w in ("cfg3", "cfg4", "cfg4_packed", "cfg5", "cfg4_predict"):
     shutil.copy(os.path.join(src, f"{w}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{w}_kernel_stats.csv"))
 
 traffic = {}
-for w in ("cfg3", "cfg4"):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", "r2", f"pmc_{w}_fetch", "*counter_collection.csv"))[0]
-    g = glob.glob(os.path.join(ROOT, "gpurun_out", "r2", f"pmc_{w}_write", "*counter_collection.csv"))[0]
+for w in ("cfg3", "cfg4", "cfg4_packed"):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", rdir, f"pmc_{w}_fetch", "*counter_collection.csv"))[0]
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", rdir, f"pmc_{w}_write", "*counter_collection.csv"))[0]
     out = os.path.join(dst, f"{tag}_{w}_pmc_traffic.csv")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_prof.py"), "pmc", f, g, out])
     mb = {}
     for r in csv.DictReader(l for l in open(out) if not l.startswith("#")):
-        mb[re.sub(r"<.*", "", r["kernel"])] = float(r["hbm_mb_corrected"])
+        # one entry per kernel NAME: the template instances of a name (bin_kernel<.., true> the scatter,
+        # bin_kernel<.., false> the count) are ADDED -- round 2 overwrote one with the other
+        key = re.sub(r"<.*", "", r["kernel"])
+        mb[key] = mb.get(key, 0.0) + float(r["hbm_mb_corrected"])
     traffic[w] = mb
 
 
@@ -72,15 +76,22 @@ with open(os.path.join(dst, f"{tag}_cfg4_pmc_lds.csv"), "w") as f:
         f.write(f"\"{k}\",{n},{b},{d.get('SQ_LDS_IDX_ACTIVE', 0)},{d.get('SQ_LDS_BANK_CONFLICT', 0)},"
                 f"{d.get('SQ_INSTS_MFMA', 0)},{(d.get('SQ_LDS_IDX_ACTIVE', 0) / b if b else 0):.3f}\n")
 
-t4, t3 = traffic["cfg4"], traffic["cfg3"]
-decoder = next(v for k, v in t4.items() if k.startswith("tiny_mlp"))
-bwd4 = sum(v for k, v in t4.items() if k.startswith(("bin_kernel", "dense_and_accumulate", "bin_finalize", "bin_chunk_scan",
-                                                      "bin_prefix", "bin_accumulate")))
+t3 = traffic["cfg3"]
 tj = os.path.join(dst, "traffic.json")
 d = json.load(open(tj))
-d["cfg4"] = {"mlp_fused": int((decoder + t4.get("slab_reduce_kernel", 0)) * 1e6), "hashgrid_bwd": int(bwd4 * 1e6),
-             "hashgrid_fwd": int(next(v for k, v in t4.items() if k.startswith("hashgrid_fwd")) * 1e6),
-             "adam": int(t4["adam_kernel"] * 1e6)}
+d["_comment"] = (f"HBM bytes per launch of each bench.py phase, from profiles/{tag}_cfg{{3,4,4_packed}}_pmc_traffic.csv "
+                 "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2*FETCH + WRITE as MI355X_MICROARCH.md "
+                 "prescribes for gfx950). cfg4 = f32 table-gradient records (the headline), cfg4_packed = "
+                 "bwd_records 1. Read by bench.py for roofline.traffic.")
+for name in ("cfg4", "cfg4_packed"):
+    t4 = traffic[name]
+    decoder = next(v for k, v in t4.items() if k.startswith("tiny_mlp"))
+    bwd4 = sum(v for k, v in t4.items() if k.startswith(("bin_kernel", "dense_and_accumulate", "bin_finalize",
+                                                          "bin_chunk_scan", "bin_prefix", "bin_accumulate",
+                                                          "dense_absmax", "dense_level")))
+    d[name] = {"mlp_fused": int((decoder + t4.get("slab_reduce_kernel", 0)) * 1e6), "hashgrid_bwd": int(bwd4 * 1e6),
+               "hashgrid_fwd": int(next(v for k, v in t4.items() if k.startswith("hashgrid_fwd")) * 1e6),
+               "adam": int(t4["adam_kernel"] * 1e6)}
 split = t3.get("siren_split_weights_kernel", 0) / 2  # launched by the forward and by the backward entry
 d["cfg3"] = {"mlp_fwd": int((t3["siren_forward_kernel"] + t3.get("siren_fwd_reduce_kernel", 0) + split) * 1e6),
              "mlp_bwd": int((t3["siren_backward_kernel"] + t3.get("siren_bwd_reduce_kernel", 0) + split +
