@@ -282,11 +282,18 @@ def main():
                     help="total training steps before the PSNR evaluation (0 = skip; default 2000, "
                          "SIREN workloads 200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-group", type=int, default=1,
+                    help="batches produced per launch pair of the on-device producer (BatchPipeline.group): the "
+                         "same batches bit for bit, produced once in `group` steps instead of beside every lookup "
+                         "(measured: the lookup gets its 8 us back, the step does not -- the work only moves)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
     ap.add_argument("--phase-every", type=int, default=8,
                     help="bracket the phases with HIP events on every n-th timed step only: "
                          "an event pair stalls the queue ~15 us, 5 pairs per step cost 8 %%")
+    ap.add_argument("--fixed-batch", action="store_true",
+                    help="diagnostic: train on the first batch over and over (no batch is produced inside the "
+                         "timed steps): what the on-device batch producer costs a step; never a measured line")
     ap.add_argument("--bwd-method", type=int, default=0)
     ap.add_argument("--split", type=float, default=None,
                     help="fraction of the batch in the first slice of the fused decoder step "
@@ -390,7 +397,7 @@ def main():
     # shuffled batches, epoch after epoch; batch k+1 is produced while step k runs (queued on
     # the step's side stream, or after Adam when the step has none): its kernels still execute
     # inside the timed region
-    pipe = datamodules.BatchPipeline(loader)
+    pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group)
 
     def one_step():
         k = counter[0]
@@ -398,11 +405,13 @@ def main():
         step.phase_events = events if sampling[0] and (k - leg_start[0]) % max(1, args.phase_every) == 0 \
             else None
         coords, target = pipe.current()
+        if args.fixed_batch:
+            return step.train_step(coords, target, lambda: coords)
         if args.no_prefetch:
             loss = step.train_step(coords, target)
             pipe.produce_next()
         else:
-            loss = step.train_step(coords, target, pipe.produce_next)
+            loss = step.train_step(coords, target, pipe.produce_next, late_work=pipe.produce_late)
         pipe.advance()
         return loss
 
@@ -492,7 +501,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "arithmetic": arithmetic(args.records), "records": args.records,
-            "data": data_name,
+            "data": data_name + (" -- DIAGNOSTIC --fixed-batch: one batch reused, not a measured line"
+                                 if args.fixed_batch else ""),
             "config": {"workload": f"{args.workload}: {'x'.join(map(str, w['shape']))} "
                                    f"{'sample volume' if w.get('sample_volume') else 'analytic phantom'}"
                                    f", {w['model']}, batch {w['batch']} coords per GPU"

@@ -209,52 +209,96 @@ def sharded_loader(dataset: MriImage, batch_size: int, rank: int = 0, world: int
 
 
 class BatchPipeline:
-    """Two reused batch buffers for a training loop: while step k consumes buffer k % 2, batch
-    k+1 is produced into the other one by `produce_next()`, which the caller runs on whatever
-    stream has room beside the step -- FusedStep queues it on its side stream right after the
-    counting stage of the table gradient, whose completion the main stream awaits anyway (no
-    extra cross-stream wait, which costs ~12 us of queue bubble on this GPU).  The counterpart
-    of the reference DataLoader's worker processes (datamodules.py:198-205).
+    """Reused batch buffers for a training loop: while step k consumes its batch, later batches are
+    produced into the other buffer by `produce_next()` / `produce_late()`, which the caller runs on
+    whatever stream has room beside the step -- FusedStep queues them on its side stream behind the
+    counting stage of the table gradient, whose completion the main stream awaits anyway (no extra
+    cross-stream wait, which costs ~12 us of queue bubble on this GPU).  The counterpart of the
+    reference DataLoader's worker processes (datamodules.py:198-205).
 
-    Ordering contract: produce_next() for batch k+1 must be queued after step k-1 has finished
-    with that buffer (true for any stream that waited on the main stream during step k), and
-    step k+1 must wait for it (FusedStep's wait for the side stream before the scatter)."""
+    `group` = R batches are produced by ONE pair of launches (sample + gather over R x batch_size
+    positions of the epoch's permutation -- the same indices, coordinates and targets the R single
+    launches give, bit for bit).  The two small kernels of a production run beside the lookup and cost
+    the step ~8 us at BASELINE config 4 (bench.py --fixed-batch); with R = 8 they run once in 8 steps --
+    measured: the lookup then takes 0.101 instead of 0.108 ms, the step the same 0.528 ms (eight times
+    longer kernels every eighth step take from their neighbours what the short ones took), so the
+    default stays 1.
+    Groups never straddle an epoch (its last group is shorter).  Two buffers of R batches alternate.
 
-    def __init__(self, loader: DeviceLoader):
+    Ordering contract: group G+1 is produced during the FIRST step of group G, on a stream that waited
+    for the main stream at that step's start (group G-1, the buffer's previous user, is then done), and
+    every later step is ordered behind that stream (FusedStep: the batch event of the previous step)."""
+
+    def __init__(self, loader: DeviceLoader, group: int = 1):
         self.loader = loader
+        self.group = max(1, int(group))
         dev, bs = loader.ds.device, loader.batch_size
-        self.slots = [(torch.empty(bs, dtype=torch.int64, device=dev),
-                       torch.empty(bs, loader.ds.dim_in, device=dev),
-                       torch.empty(bs, 1, device=dev)) for _ in range(2)]
+        rows = bs * self.group
+        self.slots = [(torch.empty(rows, dtype=torch.int64, device=dev),
+                       torch.empty(rows, loader.ds.dim_in, device=dev),
+                       torch.empty(rows, 1, device=dev)) for _ in range(2)]
         self.per_epoch = len(loader)
         if self.per_epoch == 0:
             raise ValueError("empty loader")
+        self.groups_per_epoch = -(-self.per_epoch // self.group)
         self.epoch0 = loader.epoch
         self.k = 0
-        self.sizes = [0, 0]
-        self._produce(0)  # on the current stream
+        self._made = [-1, -1]  # group number each buffer holds
+        self._due = None
+        self._produce_group(0)  # on the current stream
 
-    def _produce(self, k: int):
-        epoch, b = self.epoch0 + k // self.per_epoch, k % self.per_epoch
-        first, n = self.loader.span(b)
-        idx, coords, target = self.slots[k % 2]
-        self.loader.ds.batch(self.loader.indices(first, n, epoch, out=idx[:n]), coords[:n],
-                             target[:n])
-        self.sizes[k % 2] = n
+    def _locate(self, k: int):
+        """batch k -> (group number, epoch, first batch of the group in its epoch, batches in the group,
+        position of batch k inside the group)."""
+        e, b = divmod(k, self.per_epoch)
+        j = b // self.group
+        b0 = j * self.group
+        return e * self.groups_per_epoch + j, self.epoch0 + e, b0, min(self.group, self.per_epoch - b0), b - b0
+
+    def _produce_group(self, g: int):
+        e, j = divmod(g, self.groups_per_epoch)
+        b0 = j * self.group
+        count = min(self.group, self.per_epoch - b0)
+        first, _ = self.loader.span(b0)
+        total = sum(self.loader.span(b0 + r)[1] for r in range(count))  # only an epoch's last batch is short
+        idx, coords, target = self.slots[g % 2]
+        self.loader.ds.batch(self.loader.indices(first, total, self.epoch0 + e, out=idx[:total]),
+                             coords[:total], target[:total])
+        self._made[g % 2] = g
+
+    def _view(self, k: int):
+        g, _, b0, _, r = self._locate(k)
+        if self._made[g % 2] != g:  # a caller that never ran produce_late(): produce now, on this stream
+            self._produce_group(g)
+        lo = r * self.loader.batch_size
+        n = self.loader.span(b0 + r)[1]
+        _, coords, target = self.slots[g % 2]
+        return coords[lo:lo + n], target[lo:lo + n]
 
     def current(self):
-        """(coords, targets) of batch k; valid until advance() + produce_next()."""
-        _, coords, target = self.slots[self.k % 2]
-        n = self.sizes[self.k % 2]
-        return coords[:n], target[:n]
+        """(coords, targets) of batch k; valid until the buffer's next production."""
+        return self._view(self.k)
 
     def produce_next(self):
-        """Queue the production of batch k+1 on the CURRENT stream; returns its coordinates (the
+        """To be queued during step k: makes sure batch k+1 exists and returns its coordinates (the
         tensor current() yields after advance()), so that a caller can start coordinate-only work of
-        the next step -- FusedStep counts the table-gradient records a step ahead."""
-        self._produce(self.k + 1)
-        _, coords, _ = self.slots[(self.k + 1) % 2]
-        return coords[:self.sizes[(self.k + 1) % 2]]
+        the next step -- FusedStep counts the table-gradient records a step ahead.  With group = 1
+        batch k+1 is produced here; with larger groups it was produced a group ago, and the NEXT
+        group's production is left to produce_late() when this is the first step of a group."""
+        g, _, _, _, r = self._locate(self.k)
+        g_next = self._locate(self.k + 1)[0]
+        if self._made[g_next % 2] != g_next:
+            self._produce_group(g_next)  # batch k+1 does not exist yet (group = 1; one-batch groups)
+        elif r == 0 and g_next == g and self._made[(g + 1) % 2] != g + 1:
+            self._due = g + 1            # first of several steps on this group: the next one, late
+        return self._view(self.k + 1)[0]
+
+    def produce_late(self):
+        """The deferred production of the next group, to be queued BEHIND whatever the step needs soon
+        (FusedStep: behind the count of the next batch's records): its kernels are `group` times longer."""
+        if self._due is not None:
+            g, self._due = self._due, None
+            self._produce_group(g)
 
     def advance(self):
         self.k += 1

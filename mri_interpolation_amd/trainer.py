@@ -584,7 +584,7 @@ class FusedStep:
                                head_done=True)
 
     def train_step(self, coords, target, side_work=None, first=True, step=True,
-                   divisor=1.0) -> torch.Tensor:
+                   divisor=1.0, late_work=None) -> torch.Tensor:
         """One batch: forward, loss, backward and -- with `step` -- gradient reduction and Adam;
         returns the (device) loss scalar of this rank's batch.  Gradient accumulation over k
         batches: first=True on the first one, step=True on the last, divisor=k on all.
@@ -592,7 +592,10 @@ class FusedStep:
         on the side stream behind the counting stage when there is one, else after Adam.
         Contract: if side_work() returns a CUDA tensor, that tensor IS the `coords` of the next
         train_step call and is not modified in between -- with `count_ahead` its table-gradient
-        records are counted during this step (forget_ahead() drops such a count)."""
+        records are counted during this step (forget_ahead() drops such a count).
+        `late_work()` (e.g. BatchPipeline.produce_late: the production of a whole GROUP of later batches)
+        is queued on the same stream behind that count, so that nothing the next step waits for sits
+        behind it."""
         if self._batch_event is not None:  # this batch was produced on the side stream during the last step
             torch.cuda.current_stream().wait_event(self._batch_event)
             self._batch_event = None
@@ -640,7 +643,12 @@ class FusedStep:
                         ev = torch.cuda.Event()
                         ev.record(self._side)
                         self._ahead = dict(ptr=nxt.data_ptr(), n=nxt.shape[0], ws=other, event=ev)
+                    if late is not None:
+                        with torch.cuda.stream(self._side):
+                            late()
+                        # (a later step's wait for ITS batch event, recorded on this stream, covers it)
 
+                late, late_work = late_work, None
                 queue_side()
         if self.use_chain and self.chain_loss:
             self._pending = []
@@ -652,6 +660,8 @@ class FusedStep:
         if not step:
             if side_work is not None:
                 side_work()
+            if late_work is not None:
+                late_work()
             return self.loss
         if self.world > 1 and self.dp_mode == "reduce_scatter":
             with self._phase("all_reduce"):
@@ -694,6 +704,8 @@ class FusedStep:
                 self.opt.step()
         if side_work is not None:
             side_work()
+        if late_work is not None:
+            late_work()
         return self.loss
 
 
@@ -702,7 +714,8 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
                  precision: int = 32, log_every: int = 0, distributed: bool = True,
-                 accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1):
+                 accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1,
+                 batch_group: int = 1):
         """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
         each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
         does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
@@ -718,6 +731,7 @@ class Trainer:
             raise ValueError(f"dp_mode {dp_mode!r} not in ('all_reduce', 'reduce_scatter')")
         self.dp_mode = dp_mode  # how a data-parallel FusedStep exchanges gradients, see there
         self.grad_buckets = int(grad_buckets)  # level groups of the table gradient's reduction, see there
+        self.batch_group = int(batch_group)    # batches per launch of the on-device producer (BatchPipeline)
         self.rank, self.world = 0, 1
         if distributed:
             rank, world, _ = parallel.env_world()
@@ -775,7 +789,7 @@ class Trainer:
         if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
                 and len(train_dataloaders) > 0:
             train_dataloaders.set_epoch(0)
-            pipe = BatchPipeline(train_dataloaders)
+            pipe = BatchPipeline(train_dataloaders, group=self.batch_group)
             self.fused.forget_ahead()  # a new pipeline: nothing counted earlier is about its batches
         for epoch in range(self.max_epochs):
             if pipe is None and hasattr(train_dataloaders, "set_epoch"):
@@ -797,7 +811,7 @@ class Trainer:
                     final = (epoch == self.max_epochs - 1 and batch_idx == n_batches - 1) \
                         or (stepping and 0 < self.max_steps <= self.global_step + 1)
                     loss = self.fused.train_step(x, y, None if final else pipe.produce_next,
-                                                 **group)
+                                                 late_work=None if final else pipe.produce_late, **group)
                     if not final:
                         pipe.advance()
                 elif self.fused is not None:

@@ -329,3 +329,36 @@ def test_launcher_checkpoint_resumes_parameters_and_optimizer(amd, tmp_path):
     r = torch.load(resumed[0], weights_only=True)
     rs = r["optimizer_states"][0]["state"]
     assert all(float(s["step"]) == 2 * steps for s in rs.values()), "the optimiser's step count restarted"
+
+
+# --------------------------------------------------------------------------- batch producer
+@pytest.mark.parametrize("steps", [None, 7])
+def test_grouped_batch_production_gives_the_same_batches(amd, steps):
+    """BatchPipeline(group = R) produces R batches per launch pair: every batch -- coordinates and targets --
+    equals what the one-batch-per-launch pipeline yields, over epoch boundaries, with a short last batch
+    (steps = None) and with the cyclic fixed-step walk of a data-parallel shard (steps = 7), driven through
+    the produce_next / produce_late / advance protocol of FusedStep.train_step."""
+    dev = torch.device("cuda", 0)
+    vol = amd.datamodules.phantom_volume((20, 18, 16), device=dev)
+    ds = amd.datamodules.MriImage(volume=vol, device=dev)
+
+    def walk(group, n_batches):
+        loader = amd.datamodules.DeviceLoader(ds, 1000, shuffle=True, seed=11, lo=100, hi=5700, steps=steps)
+        pipe = amd.datamodules.BatchPipeline(loader, group=group)
+        out = []
+        for _ in range(n_batches):
+            c, t = pipe.current()
+            out.append((c.clone(), t.clone()))
+            nxt = pipe.produce_next()
+            pipe.produce_late()
+            pipe.advance()
+            assert nxt.data_ptr() == pipe.current()[0].data_ptr() and nxt.shape == pipe.current()[0].shape
+        return out
+
+    per_epoch = 7 if steps else 6      # 5600 voxels: five batches of 1000 and one of 600
+    ref = walk(1, 3 * per_epoch + 2)
+    assert [c.shape[0] for c, _ in ref[:per_epoch]] == ([1000] * 7 if steps else [1000] * 5 + [600])
+    for group in (2, 4, 8):
+        got = walk(group, 3 * per_epoch + 2)
+        for k, ((c0, t0), (c1, t1)) in enumerate(zip(ref, got)):
+            assert torch.equal(c0, c1) and torch.equal(t0, t1), (group, k)
