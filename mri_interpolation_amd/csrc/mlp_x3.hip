@@ -22,7 +22,7 @@
 //   * v_mfma_f32_16x16x32_bf16 with the weights in the A slot: the accumulator then holds, per lane,
 //     four CONSECUTIVE units of one row -- one packed 8-byte LDS store per term.
 //
-// A 32-row tile takes four workgroup barriers (see the schedule in the kernel); two waves per SIMD
+// A 32-row tile takes three workgroup barriers (see the schedule in the kernel); two waves per SIMD
 // cover each other's LDS latencies, and VALU epilogues (bias, ReLU, the exact split: 5.5
 // instructions per element) of one wave run beside the other's MFMAs.  DESIGN.md 4.9 has the
 // measurements and what was tried.
@@ -420,13 +420,20 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     }
   };
 
-  // A tile takes four workgroup barriers.  A wave's dW2 / dW1 products need the other waves' h1 / x
+  // A tile takes three (H = 128) or four workgroup barriers.  A wave's dW2 / dW1 products need the other waves' h1 / x
   // but only ITS OWN columns of dz2 / dz1 (read back transposed from the image it has just written:
   // its own LDS writes, which the LDS executes in order: no barrier), so they run in the segment that produces them, beside the
   // latency-bound loss / ReLU-mask work of the other wave on the SIMD; the next tile's layer 1 runs
   // beside dx.
-  //   B0 | S2 layer 2 -> y shares | B2 | S5 y, loss, dz2 -> image; stage x(i+1); dW2 |
-  //   B3 | S6 dz1 -> image; dW1 | B4 | S7 dx; layer 1 of tile i+1 | B0 ...
+  //   H = 128 (EARLY_L1), three barriers:
+  //   S7 dx of tile i-1; S2 layer 2 -> y shares | B2 | S5 y, loss, dz2 -> image; stage x(i+1); dW2 |
+  //   B3 | S6 dz1 -> image; dW1; layer 1 of tile i+1 | B4 | S7 dx; S2 of tile i+1 ...
+  //   H = 64 and inference, four: layer 1 of the next tile behind dx, a barrier B0 in front of layer 2
+  //   (the H = 128 order until round 3: 11.55 k cycles per tile, S7 2.56 k of them at a third of the pipe)
+  // EARLY_L1 (training, H = 128): three barriers, layer 1 of the next tile before B4 -- config 4: 11.55 k ->
+  // 11.07 k cycles per tile, kernel 0.185 -> 0.179 ms, bit-identical results; the 64-wide decoder (a quarter
+  // of the matrix work per row, latency-bound) measured 2 % slower that way and keeps the four-barrier order.
+  constexpr bool EARLY_L1 = TRAIN && H == 128;
   const int64_t tiles = (a.n + kX3Rows - 1) / kX3Rows;
   const int64_t stride = gridDim.x;
   int buf = 0;
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   }
   __syncthreads();
   layer1(0);
+  if (EARLY_L1) __syncthreads();  // h1 of the first tile complete (otherwise: B0 at the loop top)
   X3P_BEGIN
   for (int64_t tile = blockIdx.x; tile < tiles; tile += stride, buf ^= 1) {
     // opaque per tile: hipcc otherwise materialises every (a_row ^ 64 s) + ... of the tile body once,
@@ -476,7 +484,11 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       if (has_next2) load_x((tile + 2 * stride) * kX3Rows);
     };
     if (!TRAIN) stage_next();
-    X3P_SYNC(0)  // B0: h1 of this tile complete (and, inference, x of the next staged)
+    if (!EARLY_L1) {
+      X3P_SYNC(0)  // B0: h1 of this tile complete (and, inference, x of the next staged)
+    }
+    // (EARLY_L1: h1 of this tile was written before B4 of the previous tile -- or before the barrier in
+    //  front of the loop -- so layer 2 starts without a barrier, beside dx of the previous tile)
     if (GATHER && has_next2) g_coords_store(buf);  // coordinates of tile i+2 (read from S5 on: behind B2)
     // ---- S2: h2 = relu(h1 W2^T + b2); this wave's share of y ---------------------------------------
     float h2[U][TL][4];
@@ -653,7 +665,13 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         g_w1[u][1] = mma6(za, x1, g_w1[u][1]);
       }
     }
-    X3P_SYNC(4)  // B4
+    // ---- S6c: layer 1 of the NEXT tile.  h1 of this tile is dead since B3 (its last readers are layer 2
+    //      and dW2), x of the next tile was staged before B3, and this tile's ReLU mask was consumed by
+    //      the dz1 epilogue above.  In this segment the 12 MFMAs ride beside dz1 / dW1; behind B4, where
+    //      they ran until round 3, they shared a segment with dx alone (24 MFMAs on four of the eight
+    //      waves: 0.33 of the matrix pipe) and needed a barrier of their own in front of layer 2.
+    if (EARLY_L1 && has_next) layer1(buf ^ 1);
+    X3P_SYNC(4)  // B4: z1 of this tile (and, EARLY_L1, h1 of the next) complete
     if constexpr (GATHER) {
       if (has_next2) {
         float pa0, pa1;
@@ -663,7 +681,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
       }
       if (tile + 3 * stride < tiles) g_coords_load((tile + 3 * stride) * kX3Rows);
     }
-    // ---- S7: dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each); layer 1 of the next tile ---
+    // ---- S7: dx^T = W1^T dz1^T (waves 0..3: 16 features x 16 rows each).  No barrier follows: waves 4..7
+    //      go straight to layer 2 of the next tile, waves 0..3 after their 24 MFMAs -------------------------
     if (a.dx && w < 4) {
       const int kt = w & 1, bt = w >> 1;
       f32x4 c = zero4;
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         if (__float_as_uint(d1) > seen1) atomicMax(&sm.dxmax[8 * kt + 2 * g + 1], __float_as_uint(d1));
       }
     }
-    if (has_next) layer1(buf ^ 1);
+    if (!EARLY_L1 && has_next) layer1(buf ^ 1);
   }
 #undef X3_PIN
   if (TRAIN && a.dx && a.dx_absmax) {
