@@ -288,9 +288,13 @@ def main():
                          "(measured: the lookup gets its 8 us back, the step does not -- the work only moves)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
-    ap.add_argument("--phase-every", type=int, default=8,
-                    help="bracket the phases with HIP events on every n-th timed step only: "
-                         "an event pair stalls the queue ~15 us, 5 pairs per step cost 8 %%")
+    ap.add_argument("--phase-every", type=int, default=16,
+                    help="bracket the phases with HIP events on every n-th timed step only (the 4th, the (n+4)th, "
+                         "...: two samples in a 20-step run): a timing event is a serialisation point, five per "
+                         "step cost 0.15 ms (0.71 against 0.56 ms per step with n = 1, round 3)")
+    ap.add_argument("--launch", default="native", choices=["native", "graph", "eager"],
+                    help="how a step is queued (trainer.SteadyLoop): native = one mri_fused_step call per step; "
+                         "graph = hipGraph replay; eager = op by op from Python")
     ap.add_argument("--fixed-batch", action="store_true",
                     help="diagnostic: train on the first batch over and over (no batch is produced inside the "
                          "timed steps): what the on-device batch producer costs a step; never a measured line")
@@ -399,11 +403,29 @@ def main():
     # inside the timed region
     pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group)
 
+    # One GPU, fused hash-grid + tiny-MLP step: queued by ONE library call per step (trainer.SteadyLoop ->
+    # mri_fused_step: the same launches on the same data, bit-identical parameters) -- queued op by op from
+    # Python a step costs 0.2-0.55 ms of host time depending on the box, against 0.52 ms on the GPU.  The
+    # event-bracketed sample steps (every --phase-every-th) run eagerly, as do all steps with --launch eager.
+    graphed = [None]
+
+    def capture_graphs():
+        graphed[0] = None
+        if args.launch == "eager" or args.fixed_batch or args.no_prefetch or world != 1:
+            return
+        if trainer.SteadyLoop.unsupported(step, pipe) is None:
+            graphed[0] = trainer.SteadyLoop(step, pipe, mode=args.launch).capture()
+            counter[0] = pipe.k  # (its warm-up steps count as steps of the run)
+
     def one_step():
         k = counter[0]
         counter[0] += 1
-        step.phase_events = events if sampling[0] and (k - leg_start[0]) % max(1, args.phase_every) == 0 \
-            else None
+        every = max(1, args.phase_every)
+        step.phase_events = events if sampling[0] and (k - leg_start[0]) % every == min(3, every - 1) else None
+        if graphed[0] is not None:
+            if step.phase_events is not None and args.launch != "native":
+                return graphed[0].eager_step()
+            return graphed[0].step_once(sample=step.phase_events is not None)
         coords, target = pipe.current()
         if args.fixed_batch:
             return step.train_step(coords, target, lambda: coords)
@@ -429,6 +451,8 @@ def main():
         for _ in range(steps):
             loss = one_step()
         host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to QUEUE a step (host side)
+        if graphed[0] is not None:
+            graphed[0].finish()
         torch.cuda.synchronize()
         parallel.barrier()
         elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
@@ -518,6 +542,9 @@ def main():
             "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
             "phases_sampled_every": max(1, args.phase_every),
             "host_queue_ms_per_step": round(best["host_ms"], 4),
+            "launch": {"native": "one mri_fused_step call per step (phase events recorded inside the call)",
+                       "graph": "hipGraph replay per step (sample steps eager)"}[args.launch]
+            if graphed[0] is not None else "eager (queued op by op from Python)",
             "final_loss": best["loss"],
         }
         if world > 1:  # what the first real multi-GPU run needs to explain itself
@@ -552,6 +579,7 @@ def main():
                 {k: v["identical"] for k, v in legs.items()}))
         return max(ok, key=lambda k: legs[k]["value"])
 
+    capture_graphs()
     for i, (name, mode, buckets) in enumerate(plan):
         if mode is not None:
             step.dp_mode, step.grad_buckets, step._bucket_cache = mode, buckets, None
@@ -583,6 +611,8 @@ def main():
     if args.psnr_steps > 0:
         while counter[0] < args.psnr_steps:
             one_step()
+        if graphed[0] is not None:
+            graphed[0].finish()
         if rank == 0:
             preds = []
             with torch.no_grad():
@@ -614,8 +644,10 @@ def main():
             and not args.no_records_leg and args.bwd_method != 1):
         other = "packed" if args.records == "f32" else "f32"
         _lib.set_option("bwd_records", RECORDS[other][0])
+        capture_graphs()  # (a graph holds the kernels of the format it was captured under)
         leg = timed_leg(min(args.warmup, 20), args.steps)
         _lib.set_option("bwd_records", RECORDS[args.records][0])
+        capture_graphs()
         packed = dict(records=other, value=leg["value"], ms_per_step=leg["ms_per_step"],
                       phases_ms={k: round(v, 4) for k, v in sorted(leg["phases"].items())},
                       arithmetic=RECORDS[other][1])

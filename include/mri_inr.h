@@ -80,6 +80,21 @@ const char* mri_last_error(void);
  * records against float64, tests/test_gpu_round3.py). */
 int mri_set_option(const char* name, int32_t value);
 
+/* Step-dependent scalars in DEVICE memory, for callers that replay a captured step (hipGraph): a captured
+ * launch bakes its by-value arguments in, so what changes from step to step -- Adam's bias-correction
+ * prefactors (reference models.py:68-70, torch.optim.Adam: computed on the host per step) and the position
+ * of the batch in the epoch's shuffle (datamodules.py:198-205) -- is read from this block by the `_dev`
+ * entry points.  The caller fills a HOST copy with mri_step_params_fill (exactly the values mri_adam_step /
+ * mri_sample_indices derive from the same arguments: results are bit-identical) and copies it to the device
+ * (stream-ordered, e.g. hipMemcpyAsync from pinned memory) before each replay. */
+typedef struct mri_step_params {
+  float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, reserved;
+  uint64_t sample_key;   /* scrambled seed of the epoch's permutation */
+  int64_t sample_first;  /* position of the batch's first element in that permutation */
+} mri_step_params;
+int mri_step_params_fill(mri_step_params* host_out, double lr, double beta1, double beta2, double eps,
+                         int32_t step, float grad_scale, uint64_t sample_seed, int64_t sample_first);
+
 /* ---- hash-grid encoding --------------------------------------------------------------
  * Replaces, per level, the op chain of _HashGrid.forward / _HashGridV2.forward
  * (reference encoding.py:108-128, 232-270) incl. fast_hash (encoding.py:69-78), and the
@@ -407,6 +422,62 @@ int mri_mse_loss(const float* pred, const float* target, int64_t count, float gr
 int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t count, double lr, double beta1, double beta2, double eps,
                   int32_t step, float grad_scale, void* stream);
+/* The same launch with its prefactors read from a device-resident mri_step_params (hipGraph replays). */
+int mri_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      int64_t count, const mri_step_params* dev_params, void* stream);
+
+/* ---- one training step, queued by one call ----------------------------------------------------
+ * The per-batch body of the reference's training loop for its HashMLP path with the tiny-MLP decoder
+ * (reference launcher.py:156-165 pl.Trainer.fit -> models.py:61-70 training_step / backward / Adam.step, with
+ * the DataLoader of datamodules.py:198-205 producing the next batch meanwhile) as ONE host call that
+ * composes the entry points above:
+ *   side stream: [count this batch's gradient records if `counted` = 0]; sample + gather the NEXT batch;
+ *                zero its absmax buffer; count its records
+ *   main stream: lookup -> decoder forward + MSE + backward (overwriting every gradient) -> table gradient
+ *                (MRI_BWD_PREPARED | MRI_BWD_OVERWRITE) -> Adam over [param, param + n_params)
+ * The side work of a call is awaited by the next call (`join_pending` = 1) or through `ev_join`.
+ * All pointers are device pointers except `grid`, `shape`, `axis_offset` (host); streams and events are the
+ * caller's.  Feature-major (2 L, n) blocks `enc`, `d_enc`.  Same launches on the same data as the separate
+ * calls: results are bit-identical.  Why: queued op by op from an interpreter the step costs more host
+ * time than GPU time on a slow host. */
+typedef struct mri_fused_step_args {
+  const mri_grid_desc* grid;
+  float* table;                                  /* (sum T_l, F), inside the flat parameter buffer */
+  const float *w1, *b1, *w2, *b2, *w3, *b3;      /* decoder k_in -> hidden -> hidden -> 1 */
+  float *d_table, *d_w1, *d_b1, *d_w2, *d_b2, *d_w3, *d_b3, *loss;
+  int32_t hidden, bwd_method, counted, join_pending;
+  const float* coords;                           /* (n, D) this step's batch */
+  const float* target;                           /* (n) */
+  int64_t n;
+  float *enc, *d_enc;                            /* (2 L, n) each */
+  void* tiny_ws;                                 /* mri_tiny_mlp_workspace_bytes */
+  int64_t tiny_ws_bytes;
+  void* bwd_ws;                                  /* mri_hashgrid_backward_workspace_bytes, this batch's */
+  int64_t bwd_ws_bytes;
+  float* absmax;                                 /* 32 zeroed floats, or NULL (pass over d_enc instead) */
+  float *param, *grad, *exp_avg, *exp_avg_sq;    /* Adam: one range of the flat buffers */
+  int64_t n_params;
+  double lr, beta1, beta2, eps;
+  int32_t step;                                  /* 1-based */
+  float grad_scale;
+  int64_t* next_idx;                             /* NULL: no batch is produced */
+  float *next_coords, *next_target;
+  int64_t next_n;
+  void* next_bwd_ws;                             /* NULL: the next batch is not counted ahead */
+  int64_t next_bwd_ws_bytes;
+  float* next_absmax;
+  uint64_t seed;                                 /* mri_sample_indices(seed, first, lo, hi, next_n) */
+  int64_t first, lo, hi;
+  int32_t dim, reserved;
+  int64_t shape[MRI_MAX_DIM], axis_offset[MRI_MAX_DIM];
+  const float *axes, *volume;                    /* mri_gather_batch */
+  void *stream, *stream_side, *ev_fork, *ev_join;
+  void* ev_phase[5];                             /* all NULL, or five timing events recorded on `stream` around
+                                                    lookup | decoder | table gradient | Adam (a measuring caller
+                                                    brackets the phases without leaving this call) */
+} mri_fused_step_args;
+int mri_fused_step(const mri_fused_step_args* args);
+int64_t mri_fused_step_args_bytes(void); /* sizeof(mri_fused_step_args): lets a binding check its layout */
 
 /* ---- coordinate-batch producer ------------------------------------------------------------
  * Replaces MriImage.__getitem__ + DataLoader(shuffle=True) collate (reference
@@ -419,6 +490,9 @@ int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   shape / axis_offset are HOST arrays of length D. */
 int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int64_t hi, int64_t n,
                        int64_t* idx_out, void* stream);
+/* The same launch with (key of the seed, first) read from a device-resident mri_step_params. */
+int mri_sample_indices_dev(const mri_step_params* dev_params, int64_t lo, int64_t hi, int64_t n,
+                           int64_t* idx_out, void* stream);
 int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* shape,
                      const float* axes, const int64_t* axis_offset, const float* volume,
                      float* coords_out, float* target_out /* may be NULL */, void* stream);

@@ -33,6 +33,36 @@ class GridDesc(C.Structure):
     ]
 
 
+class StepParams(C.Structure):
+    """struct mri_step_params (filled on the host, copied to the device before a graph replay)."""
+    _fields_ = [("one_minus_b1", C.c_float), ("b2", C.c_float), ("one_minus_b2", C.c_float),
+                ("neg_step_size", C.c_float), ("bc2_sqrt", C.c_float), ("eps", C.c_float),
+                ("grad_scale", C.c_float), ("reserved", C.c_float),
+                ("sample_key", C.c_uint64), ("sample_first", C.c_int64)]
+
+
+class FusedStepArgs(C.Structure):
+    """struct mri_fused_step_args (host memory; every pointer a device pointer unless noted)."""
+    _fields_ = (
+        [("grid", C.POINTER(GridDesc)), ("table", C.c_void_p)]
+        + [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+        + [(k, C.c_void_p) for k in ("d_table", "d_w1", "d_b1", "d_w2", "d_b2", "d_w3", "d_b3", "loss")]
+        + [(k, C.c_int32) for k in ("hidden", "bwd_method", "counted", "join_pending")]
+        + [("coords", C.c_void_p), ("target", C.c_void_p), ("n", C.c_int64), ("enc", C.c_void_p),
+           ("d_enc", C.c_void_p), ("tiny_ws", C.c_void_p), ("tiny_ws_bytes", C.c_int64),
+           ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_int64), ("absmax", C.c_void_p)]
+        + [(k, C.c_void_p) for k in ("param", "grad", "exp_avg", "exp_avg_sq")]
+        + [("n_params", C.c_int64)] + [(k, C.c_double) for k in ("lr", "beta1", "beta2", "eps")]
+        + [("step", C.c_int32), ("grad_scale", C.c_float), ("next_idx", C.c_void_p), ("next_coords", C.c_void_p),
+           ("next_target", C.c_void_p), ("next_n", C.c_int64), ("next_bwd_ws", C.c_void_p),
+           ("next_bwd_ws_bytes", C.c_int64), ("next_absmax", C.c_void_p), ("seed", C.c_uint64),
+           ("first", C.c_int64), ("lo", C.c_int64), ("hi", C.c_int64), ("dim", C.c_int32), ("reserved", C.c_int32),
+           ("shape", C.c_int64 * MAX_DIM), ("axis_offset", C.c_int64 * MAX_DIM), ("axes", C.c_void_p),
+           ("volume", C.c_void_p)]
+        + [(k, C.c_void_p) for k in ("stream", "stream_side", "ev_fork", "ev_join")]
+        + [("ev_phase", C.c_void_p * 5)])
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
@@ -87,10 +117,15 @@ SIGNATURES = {
                                _I64, _P],
     "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
     "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
+    "mri_step_params_fill": [_P, _D, _D, _D, _D, _I32, _F, C.c_uint64, _I64],
+    "mri_fused_step": [_P],
+    "mri_adam_step_dev": [_P, _P, _P, _P, _I64, _P, _P],
+    "mri_sample_indices_dev": [_P, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
+                 "mri_fused_step_args_bytes": [],
                  "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64],
                  "mri_siren_backward_workspace_bytes": [_I64, _I32, _I32],
                  "mri_siren_forward_workspace_bytes": [_I32, _I32],

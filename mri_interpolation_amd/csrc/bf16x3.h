@@ -78,6 +78,16 @@ __device__ __forceinline__ f32x4 mma6(const Frag& a, const Frag& b, f32x4 c) {
   return c;
 }
 
+// The three largest of the nine products only: per-product error ~2^-16 |a b| (the 2^-16 terms h l, l h,
+// m m are dropped).  NOT f32-accurate per product; measured as an option for the batch-contracting weight
+// gradients only (mlp_x3.hip, MRI_DW_TERMS), where 2^18 such errors of random sign meet in one sum.
+__device__ __forceinline__ f32x4 mma3(const Frag& a, const Frag& b, f32x4 c) {
+  c = mfma16(a.m, b.h, c);
+  c = mfma16(a.h, b.m, c);
+  c = mfma16(a.h, b.h, c);
+  return c;
+}
+
 // ---- LDS images ------------------------------------------------------------------------------------
 // An activation image holds one term of a [rows][128] tile of bf16, rows of 256 bytes; 16-byte chunk
 // `ch` (8 columns) of row `row` sits at chunk ch ^ sw(row) of the row.  With this XOR (found by

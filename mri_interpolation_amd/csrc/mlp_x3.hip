@@ -35,6 +35,13 @@ namespace mri {
 namespace {
 using namespace x3;
 
+#ifndef MRI_DW_TERMS  // A/B builds: bf16 products per weight-gradient product (6 = f32-accurate; 3: see bf16x3.h mma3)
+#define MRI_DW_TERMS 6
+#endif
+__device__ __forceinline__ f32x4 mma_dw(const Frag& a, const Frag& b, f32x4 c) {
+  return MRI_DW_TERMS == 3 ? mma3(a, b, c) : mma6(a, b, c);
+}
+
 constexpr int kX3Threads = 512;
 constexpr int kX3Rows = 32;
 constexpr int kX3H = 128;
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
         if (kt + 1 < KT) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
         X3_PIN
 #pragma unroll
-        for (int u = 0; u < U; ++u) g_w2[u][kt] = mma6(za[u], hk[kt & 1], g_w2[u][kt]);
+        for (int u = 0; u < U; ++u) g_w2[u][kt] = mma_dw(za[u], hk[kt & 1], g_w2[u][kt]);
         X3_PIN
       }
     }
@@ -661,8 +668,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const Frag za = own_tr(i_z1, a_tr ^ (32 * strip(u)));
-        g_w1[u][0] = mma6(za, xk, g_w1[u][0]);
-        g_w1[u][1] = mma6(za, x1, g_w1[u][1]);
+        g_w1[u][0] = mma_dw(za, xk, g_w1[u][0]);
+        g_w1[u][1] = mma_dw(za, x1, g_w1[u][1]);
       }
     }
     // ---- S6c: layer 1 of the NEXT tile.  h1 of this tile is dead since B3 (its last readers are layer 2

@@ -30,7 +30,9 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of the current stream: torch.cuda.current_stream() builds a Stream object and resolves
+    # the device three times over (8 us per call, a dozen calls per training step: tools/host_profile.py)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _rowmajor(t: torch.Tensor) -> torch.Tensor:
@@ -717,6 +719,26 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
 
 
 # --------------------------------------------------------------------------- batch producer
+def step_params_fill(host_block: "_lib.StepParams", lr, beta1, beta2, eps, step: int, grad_scale: float,
+                     sample_seed: int, sample_first: int):
+    """Fill a HOST mri_step_params with what adam_step / sample_indices derive from these arguments."""
+    _lib.call("mri_step_params_fill", C.byref(host_block), float(lr), float(beta1), float(beta2), float(eps),
+              int(step), float(grad_scale), int(sample_seed) & 0xFFFFFFFFFFFFFFFF, int(sample_first))
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, dev_params: torch.Tensor):
+    """adam_step with its prefactors read from a device-resident mri_step_params (graph replays)."""
+    _gpu(param, grad, exp_avg, exp_avg_sq)
+    _lib.call("mri_adam_step_dev", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+              C.c_void_p(dev_params.data_ptr()), _stream())
+
+
+def sample_indices_dev(dev_params: torch.Tensor, lo: int, hi: int, n: int, out: torch.Tensor):
+    """sample_indices with (key, first) read from a device-resident mri_step_params (graph replays)."""
+    _lib.call("mri_sample_indices_dev", C.c_void_p(dev_params.data_ptr()), lo, hi, n, _ptr(out), _stream())
+    return out
+
+
 def sample_indices(seed: int, first: int, lo: int, hi: int, n: int, out=None, device="cuda"):
     if out is None:
         out = torch.empty(n, device=device, dtype=torch.int64)

@@ -14,12 +14,13 @@ gradient use the feature-major layout so the hash kernels store/load coalesced.
 Other models (e.g. the BatchNorm decoder) run `training_step` + autograd, op by op.
 """
 import contextlib
+import ctypes as C
 import time
 from typing import Dict, List, Optional
 
 import torch
 
-from . import models, ops, optim, parallel
+from . import _lib, models, ops, optim, parallel
 from .datamodules import BatchPipeline, DeviceLoader
 
 
@@ -707,6 +708,264 @@ class FusedStep:
         if late_work is not None:
             late_work()
         return self.loss
+
+
+class SteadyLoop:
+    """The fused hash-grid + tiny-MLP training step (one GPU) queued with little host work per step.
+
+    Why: a step is ~12 kernel launches, a few memsets and a stream fork / join; queued op by op from Python
+    through ctypes and torch's stream / event objects that is 0.2-0.55 ms of host time per step depending on the
+    box (tools/host_profile.py: 57 % of it interpreter and wrapper overhead) against 0.52 ms of GPU time -- on
+    a slow host the loop is HOST-bound (0.72 ms per step measured).  Two forms:
+      mode "native" (default): ONE call of the library's `mri_fused_step` per step, which composes the
+        same entry points in C (csrc/fused_step.hip);
+      mode "graph": one hipGraph per buffer parity, replayed (correct, kept for comparison -- on this runtime
+        a replay costs the host as much as the eager step).
+    Both are FusedStep.train_step's steady state with count_ahead:
+        side stream: produce batch k+1 (sample + gather) -> zero the next absmax buffer -> count batch k+1's
+                     table-gradient records;    main: lookup -> decoder -> table gradient -> Adam;    join.
+    The batch pipeline's two buffers, the two record workspaces and the two absmax buffers alternate with
+    the step's parity.  Graph mode reads what changes per step (Adam's bias-correction prefactors, the
+    shuffle position of the next batch) from a device-resident `mri_step_params` block refreshed before
+    every replay.  Same launches on the same data in the same order as the eager step: parameters are
+    bit-identical (tests/test_gpu_round3.py::test_steady_loop_equals_the_eager_loop).
+
+    Eager steps (bench.py's event-bracketed sample steps, evaluation passes) can be mixed in: the Python
+    state of FusedStep / BatchPipeline / Adam is advanced as the eager step would have left it."""
+
+    @staticmethod
+    def unsupported(step: "FusedStep", pipe: BatchPipeline) -> Optional[str]:
+        ld = pipe.loader
+        if step.world != 1:
+            return "one GPU only (collectives are not part of the step)"
+        if not (step.use_tiny and step.encoder is not None):
+            return "the fused hash-grid + tiny-MLP step only"
+        if step.overlap_forward or step.split_fraction > 0 or step.fuse_table_adam or step.bwd_method == 1:
+            return "an optional step form is selected"
+        if not (step.count_ahead and step.overlap_count):
+            return "needs count_ahead"
+        if pipe.group != 1 or not ld.shuffle:
+            return "needs a shuffled loader and BatchPipeline(group=1)"
+        if ld.steps is None and not ld.drop_last and (ld.hi - ld.lo) % ld.batch_size:
+            return "every batch must be full (drop_last, a fixed step count, or a divisible range)"
+        if ld.hi - ld.lo < ld.batch_size:
+            return "range shorter than a batch"
+        return None
+
+    def __init__(self, step: "FusedStep", pipe: BatchPipeline, mode: str = "native", ring: int = 256):
+        why = self.unsupported(step, pipe)
+        if why:
+            raise ValueError("SteadyLoop: " + why)
+        if mode not in ("native", "graph"):
+            raise ValueError("mode: native or graph")
+        self.step, self.pipe, self.mode = step, pipe, mode
+        self._wmap = self._amap = None
+        self._after_eager = True
+        self._join_pending = False
+        if mode == "graph":
+            dev = step.flat.param.device
+            self.dev_params = torch.zeros(2, 48, dtype=torch.uint8, device=dev)
+            self._host = torch.zeros(ring, 48, dtype=torch.uint8).pin_memory()
+            self._host_struct = [_lib.StepParams.from_address(self._host[i].data_ptr()) for i in range(ring)]
+            self._host_event = [None] * ring
+            self._slot = 0
+            self.graphs = [None, None]
+        else:
+            self._args = [None, None]
+            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+
+    # -- the buffers of a step of parity p (batch k in pipeline buffer p) --------------------------------
+    def _buffers(self, p: int):
+        st, pipe = self.step, self.pipe
+        n = pipe.loader.batch_size
+        q = 1 - p
+        _, coords_p, target_p = (t[:n] for t in pipe.slots[p])
+        idx_q, coords_q, target_q = (t[:n] for t in pipe.slots[q])
+        ws_p, ws_q = st._bwd_ws[self._wmap[p]], st._bwd_ws[self._wmap[q]]
+        am_p = st._absmax[self._amap[p]] if st._absmax is not None else None
+        am_q = st._absmax[self._amap[q]] if st._absmax is not None else None
+        return n, coords_p, target_p, idx_q, coords_q, target_q, ws_p, ws_q, am_p, am_q
+
+    def _enqueue(self, p: int):
+        """Graph mode: one step's launches, under capture."""
+        st = self.step
+        ld, ds, enc = self.pipe.loader, self.pipe.loader.ds, st.encoder
+        n, coords_p, target_p, idx_q, coords_q, target_q, ws_p, ws_q, am_p, am_q = self._buffers(p)
+        main = torch.cuda.current_stream()
+        st._side.wait_stream(main)
+        with torch.cuda.stream(st._side):
+            ops.sample_indices_dev(self.dev_params[p], ld.lo, ld.hi, n, idx_q)
+            ds.batch(idx_q, coords_q, target_q)
+            if am_q is not None:
+                am_q.zero_()
+            ops.hashgrid_backward_prepare(enc.desc, coords_q, st.bwd_method, st._side, ws=ws_q)
+        w = st._workspace(n, True)
+        ops.hashgrid_forward(enc.desc, coords_p, enc.table.data, out=w["enc"], feature_major=True)
+        ops.tiny_mlp_train(w["enc"], target_p, st.tiny["params"], st.tiny["grads"], st.loss, d_x=w["d_enc"],
+                           grad_divisor=1.0, overwrite=True, dx_absmax=am_p)
+        ops.hashgrid_backward(enc.desc, coords_p, w["d_enc"], st._table_grad, feature_major=True,
+                              method=st.bwd_method, prepared=True, overwrite=True, ws=ws_p, level_absmax=am_p)
+        f = st.flat
+        ops.adam_step_dev(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.dev_params[p])
+        main.wait_stream(st._side)
+
+    def _native_args(self, p: int) -> "_lib.FusedStepArgs":
+        """Native mode: the argument block of parity p; everything but the per-step scalars is fixed."""
+        st = self.step
+        ld, ds, enc = self.pipe.loader, self.pipe.loader.ds, st.encoder
+        n, coords_p, target_p, idx_q, coords_q, target_q, ws_p, ws_q, am_p, am_q = self._buffers(p)
+        w = st._workspace(n, True)
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        a = _lib.FusedStepArgs()
+        a.grid = C.pointer(enc.desc)
+        a.table = ptr(enc.table.data)
+        (w1, b1), (w2, b2), (w3, b3) = st.tiny["params"]
+        (g1, gb1), (g2, gb2), (g3, gb3) = st.tiny["grads"]
+        a.w1, a.b1, a.w2, a.b2, a.w3, a.b3 = (ptr(t) for t in (w1, b1, w2, b2, w3, b3))
+        a.d_w1, a.d_b1, a.d_w2, a.d_b2, a.d_w3, a.d_b3 = (ptr(t) for t in (g1, gb1, g2, gb2, g3, gb3))
+        a.d_table, a.loss = ptr(st._table_grad), ptr(st.loss)
+        a.hidden, a.bwd_method, a.counted = int(w1.shape[0]), int(st.bwd_method), 1
+        a.coords, a.target, a.n = ptr(coords_p), ptr(target_p), n
+        a.enc, a.d_enc = ptr(w["enc"]), ptr(w["d_enc"])
+        tiny_ws = ops._tiny_workspace(w1.shape[1], w1.shape[0], n, coords_p.device)
+        a.tiny_ws, a.tiny_ws_bytes = ptr(tiny_ws), tiny_ws.numel() * 4
+        a.bwd_ws, a.bwd_ws_bytes = ptr(ws_p), ws_p.numel() * 8
+        a.absmax = ptr(am_p)
+        f, o = st.flat, st.opt
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = ptr(f.param), ptr(f.grad), ptr(f.exp_avg), ptr(f.exp_avg_sq)
+        a.n_params = f.numel
+        a.lr, a.beta1, a.beta2, a.eps = o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.eps
+        a.grad_scale = o.grad_scale
+        a.next_idx, a.next_coords, a.next_target, a.next_n = ptr(idx_q), ptr(coords_q), ptr(target_q), n
+        a.next_bwd_ws, a.next_bwd_ws_bytes, a.next_absmax = ptr(ws_q), ws_q.numel() * 8, ptr(am_q)
+        a.lo, a.hi, a.dim = ld.lo, ld.hi, ds.dim_in
+        for d in range(ds.dim_in):
+            a.shape[d], a.axis_offset[d] = int(ds.shape[d]), int(ds.axis_offset[d])
+        a.axes, a.volume = ptr(ds.axes), ptr(ds.pixels)
+        a.stream_side = st._side.cuda_stream
+        a.ev_fork, a.ev_join = self._ev_fork.cuda_event, self._ev_join.cuda_event
+        self._keep = getattr(self, "_keep", []) + [tiny_ws]  # (the struct holds raw pointers only)
+        return a
+
+    def capture(self, warm_steps: int = 4):
+        """`warm_steps` eager steps (allocates every workspace, leaves the next batch produced and counted),
+        then the per-parity graphs (graph mode) or argument blocks (native mode)."""
+        st, pipe = self.step, self.pipe
+        for _ in range(max(2, warm_steps)):
+            self.eager_step()
+        torch.cuda.synchronize()
+        a = st._ahead
+        coords, _ = pipe.current()
+        if a is None or a["ptr"] != coords.data_ptr():
+            raise RuntimeError("SteadyLoop: the eager steps did not leave the next batch counted")
+        p0 = pipe.k % 2
+        self._wmap = {p0: a["ws"], 1 - p0: 1 - a["ws"]}
+        nxt = 1 - st._absmax_index
+        self._amap = {p0: nxt, 1 - p0: 1 - nxt}
+        if st._absmax is not None and not st._absmax_clean[nxt]:
+            st._absmax[nxt].zero_()
+            st._absmax_clean[nxt] = True
+        st._batch_event = None
+        torch.cuda.synchronize()
+        if self.mode == "graph":
+            for p in (p0, 1 - p0):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue(p)
+                self.graphs[p] = g
+        else:
+            self._ev_fork.record()  # materialises the handles
+            self._ev_join.record()
+            torch.cuda.synchronize()
+            self._keep = []
+            self._args = [self._native_args(0), self._native_args(1)]
+        self._after_eager, self._join_pending = True, False
+        return self
+
+    def eager_step(self, **kw):
+        """One step through FusedStep.train_step (same state protocol), e.g. with phase events enabled."""
+        if self._join_pending:  # the previous native step's side work (this batch, its count)
+            torch.cuda.current_stream().wait_event(self._ev_join)
+            self._join_pending = False
+        coords, target = self.pipe.current()
+        loss = self.step.train_step(coords, target, self.pipe.produce_next, **kw)
+        self.pipe.advance()
+        self._after_eager = True
+        return loss
+
+    PHASES = ("hashgrid_fwd", "mlp_fused", "hashgrid_bwd", "adam")
+
+    def step_once(self, sample: bool = False):
+        """Queue the current step; returns the (device) loss scalar.  `sample` (native mode): bracket the four
+        phases with timing events INSIDE the library call and file them under FusedStep.phase_events (an
+        eager sample step between queued ones stalls the queue for over a millisecond on this runtime)."""
+        st, pipe = self.step, self.pipe
+        k = pipe.k
+        p = k % 2
+        ld, opt = pipe.loader, st.opt
+        if self._after_eager:  # the eager step's side-stream work (next batch, its count) must be done
+            torch.cuda.current_stream().wait_stream(st._side)
+            st._batch_event = None
+            a = st._ahead
+            if a is None or a["ws"] != self._wmap[p] or (st._absmax is not None
+                                                         and 1 - st._absmax_index != self._amap[p]):
+                raise RuntimeError("SteadyLoop: buffer parity lost between eager and queued steps")
+            self._after_eager = False
+        # what changes per step: Adam's step number, the shuffle position of the NEXT batch
+        e, b = divmod(k + 1, pipe.per_epoch)
+        seed, first = ld.seed + 7919 * (pipe.epoch0 + e), ld.span(b)[0]
+        if self.mode == "graph":
+            i = self._slot = (self._slot + 1) % len(self._host_struct)
+            if self._host_event[i] is not None:
+                self._host_event[i].synchronize()  # (a ring of 256: the copy of 256 steps ago is long done)
+            ops.step_params_fill(self._host_struct[i], opt.param_groups[0]["lr"], opt.betas[0], opt.betas[1],
+                                 opt.eps, opt.step_count + 1, opt.grad_scale, seed, first)
+            self.dev_params[p].copy_(self._host[i], non_blocking=True)
+            ev = self._host_event[i] or torch.cuda.Event()
+            ev.record()
+            self._host_event[i] = ev
+            self.graphs[p].replay()
+        else:
+            a = self._args[p]
+            a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
+            a.lr = opt.param_groups[0]["lr"]
+            a.join_pending = 1 if self._join_pending else 0
+            a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+            evs = None
+            if sample and st.phase_events is not None:
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                for i, ev in enumerate(evs):
+                    ev.record()  # materialises the handle (re-recorded inside the call)
+                    a.ev_phase[i] = ev.cuda_event
+            _lib.call("mri_fused_step", C.byref(a))
+            if evs is not None:
+                for i, name in enumerate(self.PHASES):
+                    st.phase_events.setdefault(name, []).append((evs[i], evs[i + 1]))
+                    a.ev_phase[i] = None
+                a.ev_phase[4] = None
+            self._join_pending = True
+        # what an eager step would have left behind
+        opt.step_count += 1
+        pipe._made[(k + 1) % 2] = k + 1
+        pipe.advance()
+        st._ws_index = self._wmap[p]
+        st._ahead = dict(ptr=pipe.slots[1 - p][1].data_ptr(), n=ld.batch_size, ws=self._wmap[1 - p], event=None)
+        st._counted = False
+        if st._absmax is not None:
+            st._absmax_index = self._amap[p]
+            st._absmax_clean[self._amap[p]], st._absmax_clean[self._amap[1 - p]] = False, True
+        return st.loss
+
+    def finish(self):
+        """Order the current stream behind everything queued (call before reading results or going eager)."""
+        if self._join_pending:
+            torch.cuda.current_stream().wait_event(self._ev_join)
+            self._join_pending = False
+
+
+def GraphedLoop(step, pipe, **kw):
+    """SteadyLoop in hipGraph-replay form (see there)."""
+    return SteadyLoop(step, pipe, mode="graph", **kw)
 
 
 class Trainer:

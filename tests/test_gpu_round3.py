@@ -362,3 +362,59 @@ def test_grouped_batch_production_gives_the_same_batches(amd, steps):
         got = walk(group, 3 * per_epoch + 2)
         for k, ((c0, t0), (c1, t1)) in enumerate(zip(ref, got)):
             assert torch.equal(c0, c1) and torch.equal(t0, t1), (group, k)
+
+
+# --------------------------------------------------------------------------- hipGraph replays
+@pytest.mark.parametrize("mode", ["native", "graph"])
+@pytest.mark.parametrize("hidden,records", [(128, 0), (64, 0), (128, 1)])
+def test_steady_loop_equals_the_eager_loop(amd, hidden, records, mode):
+    """trainer.SteadyLoop queues the fused step with ONE library call (`mri_fused_step`, mode native) or replays
+    it as one hipGraph per buffer parity (mode graph: Adam's prefactors and the next batch's shuffle position
+    read from a device-resident mri_step_params block): after 70 steps over several epochs -- eager steps mixed
+    in, as bench.py's event-bracketed sample steps are -- parameters, both Adam moments and the step count
+    equal the eager loop's bit for bit."""
+    amd.lib.set_option("bwd_records", records)
+    dev = torch.device("cuda", 0)
+    vol = amd.datamodules.phantom_volume((40, 40, 40), device=dev)
+    ds = amd.datamodules.MriImage(volume=vol, device=dev)
+
+    def build():
+        torch.manual_seed(1337)
+        net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=hidden, n_layers=3, activation=torch.nn.ReLU,
+                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
+        step = amd.trainer.FusedStep(net, net.configure_optimizers())
+        step.count_ahead = True
+        loader = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=True, seed=1337)
+        return net, step, amd.datamodules.BatchPipeline(loader)
+
+    n_steps = 70
+    _, eager, pipe_e = build()
+    losses_e = []
+    for _ in range(n_steps):
+        c, t = pipe_e.current()
+        losses_e.append(float(eager.train_step(c, t, pipe_e.produce_next)))
+        pipe_e.advance()
+    _, st, pipe_g = build()
+    loop = amd.trainer.SteadyLoop(st, pipe_g, mode=mode).capture(warm_steps=4)
+    done = 4
+    assert pipe_g.k == done and st.opt.step_count == done
+    losses_g = []
+    while done < n_steps:
+        if done in (20, 21, 37):  # eager steps in between, odd and even parity, back to back and alone
+            losses_g.append(float(loop.eager_step()))
+        else:
+            losses_g.append(float(loop.step_once()))
+        done += 1
+    loop.finish()
+    torch.cuda.synchronize()
+    amd.lib.set_option("bwd_records", 0)
+    assert losses_g == losses_e[4:], "losses differ"
+    assert st.opt.step_count == eager.opt.step_count == n_steps and pipe_g.k == pipe_e.k
+    assert torch.equal(st.flat.param, eager.flat.param), "parameters differ"
+    assert torch.equal(st.flat.exp_avg, eager.flat.exp_avg) and torch.equal(st.flat.exp_avg_sq, eager.flat.exp_avg_sq)
+    # the loop refuses what it cannot replay
+    _, st2, pipe2 = build()
+    st2.world = 2
+    assert "one GPU" in amd.trainer.SteadyLoop.unsupported(st2, pipe2)
+    short = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=False, seed=1)
+    assert "full" in amd.trainer.SteadyLoop.unsupported(st, amd.datamodules.BatchPipeline(short))

@@ -6,7 +6,7 @@ o=gpurun_out/$MRI_ROUND/final; mkdir -p $o
 parts=${@:-bench prof pmc}
 run() { local name=$1 limit=$2; shift 2; timeout -k 10 "$limit" "$@" > "$o/$name.json" 2> "$o/$name.err"; local rc=$?; echo "$name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi; }
 if [[ $parts == *bench* ]]; then
-run bench_cfg4 300 python bench.py
+run bench_cfg4 600 python bench.py
 run bench_cfg2 300 python bench.py --workload cfg2
 run bench_cfg3 300 python bench.py --workload cfg3
 run bench_cfg5 300 python bench.py --workload cfg5
