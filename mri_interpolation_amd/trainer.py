@@ -742,8 +742,8 @@ class SteadyLoop:
             return "the fused hash-grid + tiny-MLP step only"
         if step.overlap_forward or step.split_fraction > 0 or step.fuse_table_adam or step.bwd_method == 1:
             return "an optional step form is selected"
-        if not (step.count_ahead and step.overlap_count):
-            return "needs count_ahead"
+        if not step.overlap_count:
+            return "needs the counting stage on the side stream"
         if pipe.group != 1 or not ld.shuffle:
             return "needs a shuffled loader and BatchPipeline(group=1)"
         if ld.steps is None and not ld.drop_last and (ld.hi - ld.lo) % ld.batch_size:
@@ -758,6 +758,8 @@ class SteadyLoop:
             raise ValueError("SteadyLoop: " + why)
         if mode not in ("native", "graph"):
             raise ValueError("mode: native or graph")
+        if mode == "graph" and not step.count_ahead:
+            raise ValueError("SteadyLoop: the graph form needs count_ahead")
         self.step, self.pipe, self.mode = step, pipe, mode
         self._wmap = self._amap = None
         self._after_eager = True
@@ -830,6 +832,8 @@ class SteadyLoop:
         tiny_ws = ops._tiny_workspace(w1.shape[1], w1.shape[0], n, coords_p.device)
         a.tiny_ws, a.tiny_ws_bytes = ptr(tiny_ws), tiny_ws.numel() * 4
         a.bwd_ws, a.bwd_ws_bytes = ptr(ws_p), ws_p.numel() * 8
+        if not st.count_ahead:  # the 64-wide decoder: every batch is counted inside its own step
+            a.counted = 0
         a.absmax = ptr(am_p)
         f, o = st.flat, st.opt
         a.param, a.grad, a.exp_avg, a.exp_avg_sq = ptr(f.param), ptr(f.grad), ptr(f.exp_avg), ptr(f.exp_avg_sq)
@@ -838,6 +842,8 @@ class SteadyLoop:
         a.grad_scale = o.grad_scale
         a.next_idx, a.next_coords, a.next_target, a.next_n = ptr(idx_q), ptr(coords_q), ptr(target_q), n
         a.next_bwd_ws, a.next_bwd_ws_bytes, a.next_absmax = ptr(ws_q), ws_q.numel() * 8, ptr(am_q)
+        if not st.count_ahead:
+            a.next_bwd_ws, a.next_bwd_ws_bytes = None, 0
         a.lo, a.hi, a.dim = ld.lo, ld.hi, ds.dim_in
         for d in range(ds.dim_in):
             a.shape[d], a.axis_offset[d] = int(ds.shape[d]), int(ds.axis_offset[d])
@@ -856,10 +862,13 @@ class SteadyLoop:
         torch.cuda.synchronize()
         a = st._ahead
         coords, _ = pipe.current()
-        if a is None or a["ptr"] != coords.data_ptr():
-            raise RuntimeError("SteadyLoop: the eager steps did not leave the next batch counted")
         p0 = pipe.k % 2
-        self._wmap = {p0: a["ws"], 1 - p0: 1 - a["ws"]}
+        if not st.count_ahead:
+            self._wmap = {0: st._ws_index, 1: st._ws_index}
+        elif a is None or a["ptr"] != coords.data_ptr():
+            raise RuntimeError("SteadyLoop: the eager steps did not leave the next batch counted")
+        else:
+            self._wmap = {p0: a["ws"], 1 - p0: 1 - a["ws"]}
         nxt = 1 - st._absmax_index
         self._amap = {p0: nxt, 1 - p0: 1 - nxt}
         if st._absmax is not None and not st._absmax_clean[nxt]:
@@ -907,8 +916,8 @@ class SteadyLoop:
             torch.cuda.current_stream().wait_stream(st._side)
             st._batch_event = None
             a = st._ahead
-            if a is None or a["ws"] != self._wmap[p] or (st._absmax is not None
-                                                         and 1 - st._absmax_index != self._amap[p]):
+            if (st.count_ahead and (a is None or a["ws"] != self._wmap[p])) or (
+                    st._absmax is not None and 1 - st._absmax_index != self._amap[p]):
                 raise RuntimeError("SteadyLoop: buffer parity lost between eager and queued steps")
             self._after_eager = False
         # what changes per step: Adam's step number, the shuffle position of the NEXT batch
@@ -949,7 +958,8 @@ class SteadyLoop:
         pipe._made[(k + 1) % 2] = k + 1
         pipe.advance()
         st._ws_index = self._wmap[p]
-        st._ahead = dict(ptr=pipe.slots[1 - p][1].data_ptr(), n=ld.batch_size, ws=self._wmap[1 - p], event=None)
+        st._ahead = dict(ptr=pipe.slots[1 - p][1].data_ptr(), n=ld.batch_size, ws=self._wmap[1 - p],
+                         event=None) if st.count_ahead else None
         st._counted = False
         if st._absmax is not None:
             st._absmax_index = self._amap[p]
