@@ -854,10 +854,11 @@ class SteadyLoop:
         return a
 
     def capture(self, warm_steps: int = 4):
-        """`warm_steps` eager steps (allocates every workspace, leaves the next batch produced and counted),
-        then the per-parity graphs (graph mode) or argument blocks (native mode)."""
+        """`warm_steps` eager steps (at least two before the first capture: they allocate every workspace and
+        leave the next batch produced and counted), then the per-parity graphs (graph mode) or argument
+        blocks (native mode)."""
         st, pipe = self.step, self.pipe
-        for _ in range(max(2, warm_steps)):
+        for _ in range(warm_steps):  # (0: the caller's own eager steps have established the steady state)
             self.eager_step()
         torch.cuda.synchronize()
         a = st._ahead
@@ -984,7 +985,7 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
                  precision: int = 32, log_every: int = 0, distributed: bool = True,
                  accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1,
-                 batch_group: int = 1):
+                 batch_group: int = 1, native_steps: bool = True):
         """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
         each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
         does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
@@ -1001,6 +1002,7 @@ class Trainer:
         self.dp_mode = dp_mode  # how a data-parallel FusedStep exchanges gradients, see there
         self.grad_buckets = int(grad_buckets)  # level groups of the table gradient's reduction, see there
         self.batch_group = int(batch_group)    # batches per launch of the on-device producer (BatchPipeline)
+        self.native_steps = bool(native_steps)  # queue steady-state steps with one library call (SteadyLoop)
         self.rank, self.world = 0, 1
         if distributed:
             rank, world, _ = parallel.env_world()
@@ -1060,6 +1062,12 @@ class Trainer:
             train_dataloaders.set_epoch(0)
             pipe = BatchPipeline(train_dataloaders, group=self.batch_group)
             self.fused.forget_ahead()  # a new pipeline: nothing counted earlier is about its batches
+        # one library call per step (SteadyLoop, native form) once the first eager steps have set up the
+        # steady state -- same launches on the same data, bit-identical parameters
+        loop, eager_done = None, 0
+        if pipe is not None and self.native_steps and SteadyLoop.unsupported(self.fused, pipe) is None \
+                and all(k == 1 for k in self.accumulate.values()):
+            loop = SteadyLoop(self.fused, pipe, mode="native")
         for epoch in range(self.max_epochs):
             if pipe is None and hasattr(train_dataloaders, "set_epoch"):
                 train_dataloaders.set_epoch(epoch)
@@ -1079,10 +1087,19 @@ class Trainer:
                 if pipe is not None:
                     final = (epoch == self.max_epochs - 1 and batch_idx == n_batches - 1) \
                         or (stepping and 0 < self.max_steps <= self.global_step + 1)
-                    loss = self.fused.train_step(x, y, None if final else pipe.produce_next,
-                                                 late_work=None if final else pipe.produce_late, **group)
-                    if not final:
-                        pipe.advance()
+                    if loop is not None and eager_done >= 4 and not final:
+                        if loop._wmap is None:
+                            loop.capture(warm_steps=0)
+                        loss = loop.step_once()
+                    else:
+                        if loop is not None:
+                            loop.finish()
+                            loop._after_eager = True
+                        loss = self.fused.train_step(x, y, None if final else pipe.produce_next,
+                                                     late_work=None if final else pipe.produce_late, **group)
+                        eager_done += 1
+                        if not final:
+                            pipe.advance()
                 elif self.fused is not None:
                     loss = self.fused.train_step(x, y, **group)
                 else:
@@ -1106,6 +1123,8 @@ class Trainer:
                 if stepping and 0 < self.max_steps <= self.global_step:
                     done = True
                     break
+            if loop is not None:
+                loop.finish()
             torch.cuda.synchronize()
             if self.fused is not None and self.fused.overlap_forward:
                 self.fused.check_status()  # a decoder workgroup that gave up waiting invalidates the epoch

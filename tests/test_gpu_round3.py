@@ -419,3 +419,31 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, mode):
     assert "one GPU" in amd.trainer.SteadyLoop.unsupported(st2, pipe2)
     short = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=False, seed=1)
     assert "full" in amd.trainer.SteadyLoop.unsupported(st, amd.datamodules.BatchPipeline(short))
+
+
+def test_trainer_fit_with_native_steps_equals_eager_fit(amd):
+    """Trainer.fit queues steady-state steps through SteadyLoop (one mri_fused_step call each) once four eager
+    steps have set the state up; the parameters after three epochs equal Trainer(native_steps=False)'s bit for
+    bit, the step counts agree, and a range that leaves a short last batch falls back to eager steps."""
+    dev = torch.device("cuda", 0)
+    vol = amd.datamodules.phantom_volume((32, 32, 32), device=dev)
+    ds = amd.datamodules.MriImage(volume=vol, device=dev)
+    out = []
+    for native in (True, False):
+        torch.manual_seed(1337)
+        net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
+                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
+        loader = amd.datamodules.DeviceLoader(ds, 2048, shuffle=True, seed=7)  # 32768 voxels: 16 full batches
+        tr = amd.trainer.Trainer(max_epochs=3, native_steps=native, log_every=0)
+        tr.fit(net, loader)
+        torch.cuda.synchronize()
+        out.append((tr.fused.flat.param.clone(), tr.global_step, tr.fused.opt.step_count))
+    assert out[0][1] == out[1][1] == 48 and out[0][2] == out[1][2] == 48
+    assert torch.equal(out[0][0], out[1][0]), "native steps changed the parameters"
+    torch.manual_seed(1337)
+    net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
+                             batch_norm=False, final_activation=False, lr=5e-3).cuda()
+    ragged = amd.datamodules.DeviceLoader(ds, 3000, shuffle=True, seed=7)  # last batch of an epoch: 2768 rows
+    tr = amd.trainer.Trainer(max_epochs=2, log_every=0)
+    tr.fit(net, ragged)
+    assert tr.global_step == 2 * 11 and bool(torch.isfinite(tr.fused.flat.param).all())
