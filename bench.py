@@ -187,7 +187,8 @@ def cpu_baseline(w, name):
     dt = time.perf_counter() - t0
     return dict(value=b * steps / dt, unit="coord-samples/s", cores=cores, kind="port",
                 sample=f"{steps} oracle train steps (PyTorch-CPU restatement of the reference "
-                       f"step) of {name} at batch {b} instead of {w['batch']}")
+                       f"step) of {name} at batch {b} instead of {w['batch']} (a full-size step takes the "
+                       f"host several seconds: the sample is bounded to ~12 s)")
 
 
 def run_predict(args, w, vol, step, model, rank, world, dev, data_name):
