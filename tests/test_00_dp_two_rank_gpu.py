@@ -113,3 +113,32 @@ def test_bench_two_ranks_contract(tmp_path, dp_mode):
     assert abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
     assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["exposed_ms_per_step"] >= 0.0
     assert "all_reduce" in r["phases_ms"] and "cpu_baseline" not in r
+
+
+def test_bench_one_rank_under_torchrun_is_the_plain_line(tmp_path):
+    """The scaling pass's N = 1 entry (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`, i.e. RANK=0
+    WORLD_SIZE=1 in the environment) must be the same measurement as the plain `bench.py`: no process group,
+    single-GPU parallelism, the natively queued step, the same workload and record format, a rate of the same
+    size."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: children may not be started")
+    lines = []
+    for env_extra in ({}, dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                               MASTER_PORT=str(_free_port()))):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE") if not env_extra else ():
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40",
+                            "--warmup", "10", "--psnr-steps", "0", "--no-cpu-baseline"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+        assert p.returncode == 0, p.stdout
+        out = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(out) == 1, p.stdout
+        lines.append(json.loads(out[0]))
+    plain, ranked = lines
+    for key in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "records", "config", "launch"):
+        assert plain[key] == ranked[key], key
+    assert plain["n_gpus"] == 1 and plain["config"]["parallelism"] == "single GPU" and "collectives" not in ranked
+    assert plain["launch"].startswith("one mri_fused_step call") and "packed_records" in ranked
+    assert abs(plain["value"] - ranked["value"]) <= 0.15 * plain["value"], (plain["value"], ranked["value"])
