@@ -412,7 +412,7 @@ def main():
 
     def capture_graphs():
         graphed[0] = None
-        if args.launch == "eager" or args.fixed_batch or args.no_prefetch or world != 1:
+        if args.launch == "eager" or args.fixed_batch or args.no_prefetch or (world != 1 and args.launch == "graph"):
             return
         if trainer.SteadyLoop.unsupported(step, pipe) is None:
             graphed[0] = trainer.SteadyLoop(step, pipe, mode=args.launch).capture()
@@ -557,7 +557,7 @@ def main():
                         "(phases_ms.all_reduce contains the Adam launches, phases_ms.adam is absent); "
                         "legs[*].groups: bytes of each reduction and the compute stream's wait for it",
                 "legs": {k: {"ms_per_step": round(v["ms_per_step"], 4), "value": v["value"],
-                             "dp_mode": v["dp_mode"], "grad_buckets": v["grad_buckets"],
+                             "dp_mode": v["dp_mode"], "grad_buckets": v["grad_buckets"], "launch": v.get("launch"),
                              "replicas_identical": v["identical"],
                              "exposed_ms_per_step": round(v["phases"].get("all_reduce", 0.0), 4),
                              "groups": v["groups"]} for k, v in legs.items()}}
@@ -584,6 +584,9 @@ def main():
     for i, (name, mode, buckets) in enumerate(plan):
         if mode is not None:
             step.dp_mode, step.grad_buckets, step._bucket_cache = mode, buckets, None
+            if graphed[0] is not None:
+                graphed[0].finish()
+            capture_graphs()  # (the plain all-reduce leg is queued natively, the other forms op by op)
         if i == 1 and watchdog is not None:
             watchdog.start()
         try:
@@ -595,6 +598,7 @@ def main():
                               dp_mode=mode, grad_buckets=buckets, host_ms=0.0, loss=float("nan"))
             continue
         leg.update(dp_mode=mode, grad_buckets=buckets, identical=replicas_identical(),
+                   launch="native" if graphed[0] is not None else "eager",
                    groups=[dict(bytes=b, wait_ms=round(leg["phases"].get(f"reduce_wait_{j}", 0.0), 4))
                            for j, b in enumerate(getattr(step, "last_group_bytes", []))]
                    if world > 1 else [])
@@ -606,6 +610,9 @@ def main():
     best = best_leg()
     if world > 1:  # continue (PSNR steps) in the mode the line reports
         step.dp_mode, step.grad_buckets, step._bucket_cache = legs[best]["dp_mode"], legs[best]["grad_buckets"], None
+        if graphed[0] is not None:
+            graphed[0].finish()
+        capture_graphs()
 
     # PSNR vs ground-truth voxels at a fixed step count (outside the timed region)
     psnr = None

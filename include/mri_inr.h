@@ -475,6 +475,10 @@ typedef struct mri_fused_step_args {
   void* ev_phase[5];                             /* all NULL, or five timing events recorded on `stream` around
                                                     lookup | decoder | table gradient | Adam (a measuring caller
                                                     brackets the phases without leaving this call) */
+  float grad_divisor;                            /* gradients of mean((y - t)^2) / grad_divisor; 0 = 1.  Data
+                                                    parallel: the world size, with n_params = 0 -- the caller
+                                                    reduces `grad` over the ranks and steps (mri_adam_step) */
+  float reserved2;
 } mri_fused_step_args;
 int mri_fused_step(const mri_fused_step_args* args);
 int64_t mri_fused_step_args_bytes(void); /* sizeof(mri_fused_step_args): lets a binding check its layout */

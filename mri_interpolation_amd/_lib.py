@@ -60,7 +60,7 @@ class FusedStepArgs(C.Structure):
            ("shape", C.c_int64 * MAX_DIM), ("axis_offset", C.c_int64 * MAX_DIM), ("axes", C.c_void_p),
            ("volume", C.c_void_p)]
         + [(k, C.c_void_p) for k in ("stream", "stream_side", "ev_fork", "ev_join")]
-        + [("ev_phase", C.c_void_p * 5)])
+        + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float)])
 
 
 _P = C.c_void_p

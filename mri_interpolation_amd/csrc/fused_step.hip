@@ -58,6 +58,7 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
   const mri_grid_desc* g = a->grid;
   const int64_t n = a->n, ld = n;  // feature-major blocks (2 L, n)
   const int32_t k_in = g->n_levels * g->n_features;
+  const float divisor = a->grad_divisor > 0.f ? a->grad_divisor : 1.0f;
   int rc;
   if (!a->counted) {  // this batch was not counted ahead: count it now, on the side stream (as the eager step does)
     if ((rc = mri_hashgrid_backward_prepare(g, a->coords, n, a->bwd_method, a->bwd_ws, a->bwd_ws_bytes, side)))
@@ -89,11 +90,11 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
   TRACE(5)
   if (a->absmax)
     rc = mri_tiny_mlp_train_dx_absmax(a->enc, a->target, n, k_in, a->hidden, a->w1, a->b1, a->w2, a->b2, a->w3,
-                                      a->b3, 1.0f, a->d_w1, a->d_b1, a->d_w2, a->d_b2, a->d_w3, a->d_b3, a->d_enc,
+                                      a->b3, divisor, a->d_w1, a->d_b1, a->d_w2, a->d_b2, a->d_w3, a->d_b3, a->d_enc,
                                       a->loss, nullptr, 1, a->absmax, a->tiny_ws, a->tiny_ws_bytes, main);
   else
     rc = mri_tiny_mlp_train_overwrite(a->enc, a->target, n, k_in, a->hidden, a->w1, a->b1, a->w2, a->b2, a->w3,
-                                      a->b3, 1.0f, a->d_w1, a->d_b1, a->d_w2, a->d_b2, a->d_w3, a->d_b3, a->d_enc,
+                                      a->b3, divisor, a->d_w1, a->d_b1, a->d_w2, a->d_b2, a->d_w3, a->d_b3, a->d_enc,
                                       a->loss, nullptr, a->tiny_ws, a->tiny_ws_bytes, main);
   if (rc) return rc;
   if (!phase(2)) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(phase)");
@@ -110,7 +111,8 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
     return rc;
   if (!phase(3)) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(phase)");
   TRACE(7)
-  if ((rc = mri_adam_step(a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n_params, a->lr, a->beta1, a->beta2,
+  if (a->n_params > 0 &&  // (0: a data-parallel caller reduces the gradient over the ranks first, then steps)
+      (rc = mri_adam_step(a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n_params, a->lr, a->beta1, a->beta2,
                           a->eps, a->step, a->grad_scale, main)))
     return rc;
   if (!phase(4)) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(phase)");

@@ -736,8 +736,8 @@ class SteadyLoop:
     @staticmethod
     def unsupported(step: "FusedStep", pipe: BatchPipeline) -> Optional[str]:
         ld = pipe.loader
-        if step.world != 1:
-            return "one GPU only (collectives are not part of the step)"
+        if step.world != 1 and (step.dp_mode != "all_reduce" or step.grad_buckets > 1):
+            return "several ranks: the plain all-reduce form only (one reduction of the flat gradient)"
         if not (step.use_tiny and step.encoder is not None):
             return "the fused hash-grid + tiny-MLP step only"
         if step.overlap_forward or step.split_fraction > 0 or step.fuse_table_adam or step.bwd_method == 1:
@@ -758,8 +758,8 @@ class SteadyLoop:
             raise ValueError("SteadyLoop: " + why)
         if mode not in ("native", "graph"):
             raise ValueError("mode: native or graph")
-        if mode == "graph" and not step.count_ahead:
-            raise ValueError("SteadyLoop: the graph form needs count_ahead")
+        if mode == "graph" and (not step.count_ahead or step.world != 1):
+            raise ValueError("SteadyLoop: the graph form needs count_ahead and one GPU")
         self.step, self.pipe, self.mode = step, pipe, mode
         self._wmap = self._amap = None
         self._after_eager = True
@@ -837,9 +837,9 @@ class SteadyLoop:
         a.absmax = ptr(am_p)
         f, o = st.flat, st.opt
         a.param, a.grad, a.exp_avg, a.exp_avg_sq = ptr(f.param), ptr(f.grad), ptr(f.exp_avg), ptr(f.exp_avg_sq)
-        a.n_params = f.numel
+        a.n_params = f.numel if st.world == 1 else 0  # several ranks: reduce, then step (step_once)
         a.lr, a.beta1, a.beta2, a.eps = o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.eps
-        a.grad_scale = o.grad_scale
+        a.grad_scale, a.grad_divisor = o.grad_scale, float(st.world)
         a.next_idx, a.next_coords, a.next_target, a.next_n = ptr(idx_q), ptr(coords_q), ptr(target_q), n
         a.next_bwd_ws, a.next_bwd_ws_bytes, a.next_absmax = ptr(ws_q), ws_q.numel() * 8, ptr(am_q)
         if not st.count_ahead:
@@ -950,10 +950,21 @@ class SteadyLoop:
             _lib.call("mri_fused_step", C.byref(a))
             if evs is not None:
                 for i, name in enumerate(self.PHASES):
-                    st.phase_events.setdefault(name, []).append((evs[i], evs[i + 1]))
+                    if st.world == 1 or name != "adam":  # (several ranks: Adam is queued below, behind the reduction)
+                        st.phase_events.setdefault(name, []).append((evs[i], evs[i + 1]))
                     a.ev_phase[i] = None
                 a.ev_phase[4] = None
             self._join_pending = True
+            if st.world > 1:  # data parallel, plain form: ONE reduction of the flat gradient, then Adam
+                st.last_group_bytes = [st.flat.grad.numel() * 4]
+                timed = sample and st.phase_events is not None
+                saved, st.phase_events = st.phase_events, (st.phase_events if timed else None)
+                with st._phase("all_reduce"), st._phase("reduce_wait_0"):
+                    parallel.all_reduce_sum(st.flat.grad)
+                with st._phase("adam"):
+                    opt.step()
+                st.phase_events = saved
+                opt.step_count -= 1  # (counted below, as for one rank)
         # what an eager step would have left behind
         opt.step_count += 1
         pipe._made[(k + 1) % 2] = k + 1

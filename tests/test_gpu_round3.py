@@ -415,8 +415,10 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, mode):
     assert torch.equal(st.flat.exp_avg, eager.flat.exp_avg) and torch.equal(st.flat.exp_avg_sq, eager.flat.exp_avg_sq)
     # the loop refuses what it cannot replay
     _, st2, pipe2 = build()
-    st2.world = 2
-    assert "one GPU" in amd.trainer.SteadyLoop.unsupported(st2, pipe2)
+    st2.world, st2.grad_buckets = 2, 4  # several ranks: only the plain all-reduce form is queued natively
+    assert "plain all-reduce" in amd.trainer.SteadyLoop.unsupported(st2, pipe2)
+    st2.grad_buckets = 1
+    assert amd.trainer.SteadyLoop.unsupported(st2, pipe2) is None
     short = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=False, seed=1)
     assert "full" in amd.trainer.SteadyLoop.unsupported(st, amd.datamodules.BatchPipeline(short))
 
