@@ -408,14 +408,17 @@ def main():
     # mri_fused_step: the same launches on the same data, bit-identical parameters) -- queued op by op from
     # Python a step costs 0.2-0.55 ms of host time depending on the box, against 0.52 ms on the GPU.  The
     # event-bracketed sample steps (every --phase-every-th) run eagerly, as do all steps with --launch eager.
-    graphed = [None]
+    graphed, launch_note = [None], [None]
 
     def capture_graphs():
         graphed[0] = None
         if args.launch == "eager" or args.fixed_batch or args.no_prefetch or (world != 1 and args.launch == "graph"):
             return
         if trainer.SteadyLoop.unsupported(step, pipe) is None:
-            graphed[0] = trainer.SteadyLoop(step, pipe, mode=args.launch).capture()
+            try:
+                graphed[0] = trainer.SteadyLoop(step, pipe, mode=args.launch).capture()
+            except (RuntimeError, ValueError) as exc:  # never lose the line to the launch form: queue eagerly
+                graphed[0], launch_note[0] = None, f"eager (the {args.launch} form was refused: {exc})"
             counter[0] = pipe.k  # (its warm-up steps count as steps of the run)
 
     def one_step():
@@ -545,7 +548,7 @@ def main():
             "host_queue_ms_per_step": round(best["host_ms"], 4),
             "launch": {"native": "one mri_fused_step call per step (phase events recorded inside the call)",
                        "graph": "hipGraph replay per step (sample steps eager)"}[args.launch]
-            if graphed[0] is not None else "eager (queued op by op from Python)",
+            if graphed[0] is not None else (launch_note[0] or "eager (queued op by op from Python)"),
             "final_loss": best["loss"],
         }
         if world > 1:  # what the first real multi-GPU run needs to explain itself
