@@ -51,7 +51,8 @@ def test_two_rank_fit_on_unequal_slabs(tmp_path):
         outs.append(out)
     assert [p.returncode for p in procs] == [0, 0], "\n".join(outs)
     report = json.load(open(tmp_path / "dp_fit.json"))
-    assert set(report) == {"hash", "hash_rs", "siren", "batchnorm", "union"}
+    assert set(report) == {"hash", "hash_rs", "hash_plain", "hash_plain_eager", "siren", "batchnorm", "union"}
+    assert report["hash_plain"]["equals_eager"]  # Trainer.fit's natively queued data-parallel steps: same bits
     # every gradient-exchange form of the fused step == one process on the concatenated batch
     union = report.pop("union")
     assert set(union) == {"all_reduce_1", "all_reduce_4", "reduce_scatter"}
@@ -63,6 +64,7 @@ def test_two_rank_fit_on_unequal_slabs(tmp_path):
         assert r["batches_per_epoch"] == 4 and r["steps_min"] == r["steps_max"], (kind, r)
         assert r["fused"] == (kind != "batchnorm"), (kind, r)
     assert report["hash"]["optimizer_steps"] == 4      # 2 epochs x 4 batches, 2 batches per step
+    assert report["hash_plain"]["optimizer_steps"] == 8
     assert report["siren"]["optimizer_steps"] == 8
 
 

@@ -87,16 +87,20 @@ def main():
     torch.cuda.set_device(local)
     vol = datamodules.phantom_volume((25, 32, 32)).cpu().numpy()
     report = {}
-    for kind in ("hash", "hash_rs", "siren", "batchnorm"):
+    finals = {}
+    for kind in ("hash", "hash_rs", "hash_plain", "hash_plain_eager", "siren", "batchnorm"):
         c = (cfg.HashConfig() if kind != "siren" else cfg.BaseConfig()).resolve(vol.shape)
         c.batch_size = 4096
         dm = datamodules.MriDataModule(config=c, volume=vol, norm_siren=kind == "siren")
         dm.prepare_data()
         loader = dm.train_dataloader(rank, world)
         net = build(kind).cuda()
+        # "hash": the bucketed, overlapped form with accumulation; "hash_plain": ONE all-reduce per step, which
+        # Trainer.fit queues through SteadyLoop (mri_fused_step, reduce, Adam) -- "hash_plain_eager" is the same
+        # run queued op by op and must end on the same bits
         tr = Trainer(max_epochs=2, accumulate_grad_batches=2 if kind == "hash" else None,
                      dp_mode="reduce_scatter" if kind == "hash_rs" else "all_reduce",
-                     grad_buckets=4 if kind == "hash" else 1)  # "hash": the bucketed, overlapped form
+                     grad_buckets=4 if kind == "hash" else 1, native_steps=kind != "hash_plain_eager")
         tr.fit(net, loader)
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
@@ -115,8 +119,11 @@ def main():
                             fused=tr.fused is not None, finite=bool(torch.isfinite(flat).all()),
                             moved=bool((flat != torch.cat([p.detach().reshape(-1) for p in
                                                            build(kind).cuda().parameters()])).any()))
+        finals[kind] = flat.clone()
         assert same, f"{kind}: replicas differ after fit"
         assert int(lo) == int(hi), f"{kind}: ranks ran {int(lo)}..{int(hi)} steps"
+    assert torch.equal(finals["hash_plain"], finals["hash_plain_eager"]), "natively queued data-parallel fit differs"
+    report["hash_plain"]["equals_eager"] = True
     report["union"] = union_check(rank, world)
     parallel.barrier()
     dist.destroy_process_group()
