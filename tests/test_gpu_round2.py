@@ -199,7 +199,7 @@ def test_full_size_cfg3_siren_intensities_and_step(amd):
     # cancel.  Yardstick: the same step in float64 (chunked, same f32 inputs); the kernel must be no
     # further from it than the f32 oracle is
     loss64, grads64 = otrain.loss_and_grads_chunked(otrain.as_double(model), x.double(), y.double(), 1 << 16)
-    assert abs(float(step.loss) - loss64) <= 2.0 * abs(float(want_loss) - loss64) + 1e-6 * loss64
+    assert abs(float(step.loss) - loss64) <= REL_TOL * loss64  # (one f32 number summed over 2^20 rows: 1e-6 is its noise)
     layers = list(net.layers) + [net.last_layer]
     for i, layer in enumerate(layers):
         assert_no_worse(layer.weight.grad.cpu().numpy(), grads[2 * i].numpy(), grads64[2 * i].numpy(), f"gw{i}")
