@@ -5,6 +5,8 @@ Instead of widening the tolerance, the HIP path and the float32 oracle (or the r
 values) are BOTH measured against the same op sequence evaluated in float64 on the same float32
 inputs: the claim under test is "the kernel is no worse an f32 evaluation than the reference's".
 """
+import os
+
 import numpy as np
 
 from conftest import rel_err
@@ -30,6 +32,9 @@ def assert_no_worse(kernel, f32_ref, f64, what="", factor=2.0, floor=FLOOR, max_
     (`max_factor`: a different factor for the max criterion, see AFTER_ADAM_MAX_FACTOR)."""
     k_max, k_l2 = rel_err(np.asarray(kernel, dtype=np.float64), np.asarray(f64, dtype=np.float64))
     r_max, r_l2 = rel_err(np.asarray(f32_ref, dtype=np.float64), np.asarray(f64, dtype=np.float64))
+    if os.environ.get("MRI_YARDSTICK_PRINT"):  # margins, for a reader of a -s run
+        print(f"yardstick {what}: kernel {k_max:.2e} / {k_l2:.2e}, reference {r_max:.2e} / {r_l2:.2e}, "
+              f"allowed {(max_factor or factor) * r_max + floor:.2e} / {factor * r_l2 + floor:.2e}")
     assert k_max <= (max_factor or factor) * r_max + floor and k_l2 <= factor * r_l2 + floor, \
         (f"{what}: kernel is {k_max:.3e} (max) / {k_l2:.3e} (L2) from float64, the f32 reference "
          f"{r_max:.3e} / {r_l2:.3e}")
