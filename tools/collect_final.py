@@ -33,7 +33,9 @@ for w in ("cfg3", "cfg4", "cfg4_packed", "cfg5", "cfg4_predict"):
     shutil.copy(os.path.join(src, f"{w}_kernel_stats.csv"), os.path.join(dst, f"{tag}_{w}_kernel_stats.csv"))
 
 traffic = {}
-for w in ("cfg3", "cfg4", "cfg4_packed"):
+for w in ("cfg3", "cfg4", "cfg4_packed", "cfg2", "cfg5"):
+    if not glob.glob(os.path.join(ROOT, "gpurun_out", rdir, f"pmc_{w}_fetch", "*counter_collection.csv")):
+        continue
     f = glob.glob(os.path.join(ROOT, "gpurun_out", rdir, f"pmc_{w}_fetch", "*counter_collection.csv"))[0]
     g = glob.glob(os.path.join(ROOT, "gpurun_out", rdir, f"pmc_{w}_write", "*counter_collection.csv"))[0]
     out = os.path.join(dst, f"{tag}_{w}_pmc_traffic.csv")
@@ -83,7 +85,9 @@ d["_comment"] = (f"HBM bytes per launch of each bench.py phase, from profiles/{t
                  "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2*FETCH + WRITE as MI355X_MICROARCH.md "
                  "prescribes for gfx950). cfg4 = f32 table-gradient records (the headline), cfg4_packed = "
                  "bwd_records 1. Read by bench.py for roofline.traffic.")
-for name in ("cfg4", "cfg4_packed"):
+for name in ("cfg4", "cfg4_packed", "cfg2", "cfg5"):
+    if name not in traffic:
+        continue
     t4 = traffic[name]
     decoder = next(v for k, v in t4.items() if k.startswith("tiny_mlp"))
     bwd4 = sum(v for k, v in t4.items() if k.startswith(("bin_kernel", "dense_and_accumulate", "bin_finalize",
