@@ -19,7 +19,7 @@ for w in cfg4 cfg3 cfg5; do bash tools/gpu_prof.sh $w --workload $w --steps 20 -
 bash tools/gpu_prof.sh cfg4_packed --steps 20 --warmup 5 --records packed --no-records-leg > $o/prof_cfg4_packed.log 2>&1 || exit 1; cp gpurun_out/$MRI_ROUND/cfg4_packed_kernel_stats.csv $o/
 bash tools/gpu_prof.sh cfg4_predict --mode predict --steps 40 --warmup 5 > $o/prof_cfg4_predict.log 2>&1 || exit 1; cp gpurun_out/$MRI_ROUND/cfg4_predict_kernel_stats.csv $o/
 fi
-if [[ $parts == *pmc* ]]; then
+if [[ " $parts " == *" pmc "* ]]; then
 for w in cfg4 cfg3 cfg2 cfg5; do
   bash tools/gpu_pmc.sh ${w}_fetch "FETCH_SIZE" --workload $w --steps 6 --warmup 2 --no-records-leg > $o/pmc_${w}_fetch.log 2>&1 || exit 1
   bash tools/gpu_pmc.sh ${w}_write "WRITE_SIZE" --workload $w --steps 6 --warmup 2 --no-records-leg > $o/pmc_${w}_write.log 2>&1 || exit 1
