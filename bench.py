@@ -289,10 +289,11 @@ def main():
                          "(measured: the lookup gets its 8 us back, the step does not -- the work only moves)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
-    ap.add_argument("--phase-every", type=int, default=16,
+    ap.add_argument("--phase-every", type=int, default=32,
                     help="bracket the phases with HIP events on every n-th timed step only (the 4th, the (n+4)th, "
-                         "...: two samples in a 20-step run): a timing event is a serialisation point, five per "
-                         "step cost 0.15 ms (0.71 against 0.56 ms per step with n = 1, round 3)")
+                         "...: one sample in a 20-step run, six in the default 200): a timing event is a "
+                         "serialisation point, five per step cost 0.15 ms (0.71 against 0.56 ms per step with "
+                         "n = 1, round 3)")
     ap.add_argument("--launch", default="native", choices=["native", "graph", "eager"],
                     help="how a step is queued (trainer.SteadyLoop): native = one mri_fused_step call per step; "
                          "graph = hipGraph replay; eager = op by op from Python")
