@@ -12,14 +12,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "libmri_x3prof.so")
+LIB = os.environ.get("MRI_X3PROF_LIB") or os.path.join(ROOT, "tools", "libmri_x3prof.so")  # A/B: another build
 
 
 def build():
     import importlib
     b = importlib.import_module("mri_interpolation_amd.build")
     srcs = [os.path.join(b.CSRC, s) for s in ("mlp_x3.hip", "mlp_fused.hip", "train_ops.hip")]
-    subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMRI_X3_PROFILE", "-shared", "-o", LIB] + srcs)
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]  # e.g. -DMRI_X3_SKEW with MRI_X3PROF_LIB=tools/other.so
+    subprocess.check_call([b._hipcc()] + b.FLAGS + ["-DMRI_X3_PROFILE"] + extra + ["-shared", "-o", LIB] + srcs)
 
 
 def main():
