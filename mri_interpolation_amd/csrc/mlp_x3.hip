@@ -52,10 +52,21 @@ constexpr int kX3H = 128;
 #ifdef MRI_X3_PROFILE
 __device__ long long* g_x3_profile = nullptr;
 constexpr int kX3ProfSlots = 32;
+#ifdef MRI_X3_CLOCK_ONLY
+// tools/x3_clock.py: the clock the tile loop runs at = shader cycles (s_memtime) per 100 MHz tick (s_memrealtime),
+// ONE pair of stamps around the whole loop (slots 24 / 25), none inside it (MI355X_MICROARCH.md, DVFS give-back 6)
+#define X3P_START
+#define X3P_BEGIN long long p_acc[kX3ProfSlots] = {}; const long long p_c0 = __builtin_amdgcn_s_memtime(), \
+                                                                    p_r0 = __builtin_amdgcn_s_memrealtime();
+#define X3P_MARK(i) if ((i) == 18) { p_acc[24] = __builtin_amdgcn_s_memtime() - p_c0; \
+                                     p_acc[25] = __builtin_amdgcn_s_memrealtime() - p_r0; }
+#define X3P_SYNC(i) __syncthreads();
+#else
 #define X3P_START const long long p_t0 = clock64();
 #define X3P_BEGIN long long p_t = clock64(); long long p_acc[kX3ProfSlots] = {}; p_acc[20] = p_t - p_t0;
 #define X3P_MARK(i) { const long long p_n = clock64(); p_acc[i] += p_n - p_t; p_t = p_n; }
 #define X3P_SYNC(i) { X3P_MARK(2 * (i)) __syncthreads(); X3P_MARK(2 * (i) + 1) }
+#endif
 #define X3P_END                                                                               \
   if (g_x3_profile && (threadIdx.x & 63) == 0) {                                              \
     long long* dst = g_x3_profile + ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kX3ProfSlots; \
