@@ -33,3 +33,16 @@ for name, c in (("shuffled", x), ("raster  ", xr), ("morton  ", xs)):
     f = timed(lambda: ops.hashgrid_forward(enc.desc, c, enc.table.data, out=out, feature_major=True))
     b = timed(lambda: ops.hashgrid_backward(enc.desc, c, d, g, feature_major=True, method=2, overwrite=True))
     print("%s: lookup %.4f ms   table gradient (count + scatter + accumulate on one stream) %.4f ms" % (name, f, b), flush=True)
+
+# per level (round 3): where the order helps the lookup and where it hurts the table gradient -- one level per call
+# (level_mask; the lookup of one level alone through a one-level grid descriptor is not available, so the lookup
+# is timed for the whole grid above and per level only the table gradient is split)
+if "--levels" in sys.argv:
+    print("table gradient per level (count + scatter + accumulate of that level alone), ms: shuffled / morton")
+    for l in range(enc.desc.n_levels):
+        t = []
+        for c in (x, xs):
+            t.append(timed(lambda: ops.hashgrid_backward(enc.desc, c, d, g, feature_major=True, method=2, overwrite=True,
+                                                         level_mask=1 << l), reps=20))
+        print("  level %2d  res %5d  slots %7d : %.4f / %.4f" % (l, int(enc.desc.resolution[l][0]),
+                                                               int(enc.desc.table_size[l]), t[0], t[1]), flush=True)
