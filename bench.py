@@ -289,6 +289,13 @@ def main():
                          "(measured: the lookup gets its 8 us back, the step does not -- the work only moves)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
+    ap.add_argument("--batch-order", choices=("morton", "shuffled"), default="shuffled",
+                    help="order of a batch's rows (the SET is the epoch's shuffle either way; the loss is a mean over "
+                         "it): 'shuffled' leaves them as the permutation yields them; 'morton' re-orders them on the "
+                         "device along a Morton curve, transposed inside blocks of 16384 rows (mri_order_batch) -- every "
+                         "kernel of the step then runs faster (lookup -8 us, scatter + accumulate -5 us) and the step "
+                         "slower, 0.536 against 0.513 ms: the sort (rocPRIM's merge path: 17 launches, ~120 us on the "
+                         "side stream) runs beside the table gradient (DESIGN.md 8)")
     ap.add_argument("--cold-start", action="store_true",
                     help="time the first leg on a device that has just left idle (the order until round 3: timed legs, "
                          "then the quality leg); by default the quality leg's training steps run first, so that every "
@@ -407,7 +414,8 @@ def main():
     # shuffled batches, epoch after epoch; batch k+1 is produced while step k runs (queued on
     # the step's side stream, or after Adam when the step has none): its kernels still execute
     # inside the timed region
-    pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group)
+    pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group,
+                                     order=args.batch_order)
 
     # One GPU, fused hash-grid + tiny-MLP step: queued by ONE library call per step (trainer.SteadyLoop ->
     # mri_fused_step: the same launches on the same data, bit-identical parameters) -- queued op by op from
@@ -576,6 +584,7 @@ def main():
         if packed is not None:
             result["packed_records"] = packed
         result["device_warmup"] = device_warmup
+        result["batch_order"] = pipe.order
         if psnr is not None:
             result["psnr"] = psnr
         if cpu is not None:

@@ -60,7 +60,9 @@ class FusedStepArgs(C.Structure):
            ("shape", C.c_int64 * MAX_DIM), ("axis_offset", C.c_int64 * MAX_DIM), ("axes", C.c_void_p),
            ("volume", C.c_void_p)]
         + [(k, C.c_void_p) for k in ("stream", "stream_side", "ev_fork", "ev_join")]
-        + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float)])
+        + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float),
+           ("order_ws", C.c_void_p), ("order_ws_bytes", C.c_int64), ("next2_idx", C.c_void_p),
+           ("seed2", C.c_uint64), ("first2", C.c_int64)])
 
 
 _P = C.c_void_p
@@ -122,10 +124,12 @@ SIGNATURES = {
     "mri_adam_step_dev": [_P, _P, _P, _P, _I64, _P, _P],
     "mri_sample_indices_dev": [_P, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
+    "mri_order_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, _I64, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
                  "mri_fused_step_args_bytes": [],
+                 "mri_order_batch_workspace_bytes": [_I64, _I32],
                  "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64],
                  "mri_siren_backward_workspace_bytes": [_I64, _I32, _I32],
                  "mri_siren_forward_workspace_bytes": [_I32, _I32],

@@ -748,6 +748,30 @@ def sample_indices(seed: int, first: int, lo: int, hi: int, n: int, out=None, de
     return out
 
 
+def order_batch_workspace(n: int, dim: int, device) -> torch.Tensor:
+    """Workspace of order_batch for batches of up to n rows (int64 tensor, 256-byte aligned by the allocator)."""
+    need = _lib.load().mri_order_batch_workspace_bytes(int(n), int(dim))
+    if need < 0:
+        raise ValueError(f"order_batch: bad n / dim ({n}, {dim})")
+    return torch.empty((need + 7) // 8, dtype=torch.int64, device=device)
+
+
+def order_batch(idx: torch.Tensor, shape: Sequence[int], ws: Optional[torch.Tensor] = None, stream=None):
+    """Reorders the flat voxel indices of ONE batch in place (mri_order_batch): Morton order over the axes of
+    `shape`, transposed inside blocks of 16384 rows -- the set is untouched, the order is the one the lookup and
+    the table-gradient kernels like best.  Deterministic."""
+    _gpu(idx)
+    if idx.dtype != torch.int64 or not idx.is_contiguous():
+        raise ValueError("order_batch: contiguous int64 indices")
+    n, dim = idx.numel(), len(shape)
+    if ws is None:
+        ws = order_batch_workspace(n, dim, idx.device)
+    shp = (C.c_int64 * dim)(*[int(s) for s in shape])
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    _lib.call("mri_order_batch", _ptr(idx), n, dim, shp, _ptr(ws), ws.numel() * 8, st)
+    return idx
+
+
 def gather_batch(idx, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],
                  volume: Optional[torch.Tensor], coords=None, target=None):
     _gpu(idx, axes, volume, coords, target)

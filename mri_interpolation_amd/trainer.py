@@ -756,6 +756,8 @@ class SteadyLoop:
         why = self.unsupported(step, pipe)
         if why:
             raise ValueError("SteadyLoop: " + why)
+        if mode == "graph" and pipe.order != "shuffled":
+            raise ValueError("SteadyLoop: ordered batches are queued natively or eagerly, not as graph replays")
         if mode not in ("native", "graph"):
             raise ValueError("mode: native or graph")
         if mode == "graph" and (not step.count_ahead or step.world != 1):
@@ -848,6 +850,9 @@ class SteadyLoop:
         for d in range(ds.dim_in):
             a.shape[d], a.axis_offset[d] = int(ds.shape[d]), int(ds.axis_offset[d])
         a.axes, a.volume = ptr(ds.axes), ptr(ds.pixels)
+        if self.pipe.order == "morton":  # batches in spatial order (ops.order_batch): indices two batches ahead
+            a.order_ws, a.order_ws_bytes = ptr(self.pipe._order_ws), self.pipe._order_ws.numel() * 8
+            a.next2_idx = ptr(self.pipe.slots[p][0][:n])  # batch k+2's slot: batch k was gathered from it a step ago
         a.stream_side = st._side.cuda_stream
         a.ev_fork, a.ev_join = self._ev_fork.cuda_event, self._ev_join.cuda_event
         self._keep = getattr(self, "_keep", []) + [tiny_ws]  # (the struct holds raw pointers only)
@@ -898,7 +903,7 @@ class SteadyLoop:
             torch.cuda.current_stream().wait_event(self._ev_join)
             self._join_pending = False
         coords, target = self.pipe.current()
-        loss = self.step.train_step(coords, target, self.pipe.produce_next, **kw)
+        loss = self.step.train_step(coords, target, self.pipe.produce_next, late_work=self.pipe.produce_late, **kw)
         self.pipe.advance()
         self._after_eager = True
         return loss
@@ -924,6 +929,11 @@ class SteadyLoop:
         # what changes per step: Adam's step number, the shuffle position of the NEXT batch
         e, b = divmod(k + 1, pipe.per_epoch)
         seed, first = ld.seed + 7919 * (pipe.epoch0 + e), ld.span(b)[0]
+        if pipe.order == "morton":  # ordered batches: the next batch's indices exist already, batch k+2's are made
+            if pipe._idx_made[(k + 1) % 2] != k + 1:  # (an eager step that queued no late work: make them now,
+                pipe._produce_indices(k + 1)          #  on this stream, in front of the call's fork)
+            e2, b2 = divmod(k + 2, pipe.per_epoch)
+            seed2, first2 = ld.seed + 7919 * (pipe.epoch0 + e2), ld.span(b2)[0]
         if self.mode == "graph":
             i = self._slot = (self._slot + 1) % len(self._host_struct)
             if self._host_event[i] is not None:
@@ -938,6 +948,8 @@ class SteadyLoop:
         else:
             a = self._args[p]
             a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
+            if pipe.order == "morton":
+                a.seed2, a.first2 = seed2 & 0xFFFFFFFFFFFFFFFF, first2
             a.lr = opt.param_groups[0]["lr"]
             a.join_pending = 1 if self._join_pending else 0
             a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
@@ -968,6 +980,8 @@ class SteadyLoop:
         # what an eager step would have left behind
         opt.step_count += 1
         pipe._made[(k + 1) % 2] = k + 1
+        if pipe.order == "morton":
+            pipe._idx_made[k % 2] = k + 2
         pipe.advance()
         st._ws_index = self._wmap[p]
         st._ahead = dict(ptr=pipe.slots[1 - p][1].data_ptr(), n=ld.batch_size, ws=self._wmap[1 - p],
@@ -996,7 +1010,7 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
                  precision: int = 32, log_every: int = 0, distributed: bool = True,
                  accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1,
-                 batch_group: int = 1, native_steps: bool = True):
+                 batch_group: int = 1, native_steps: bool = True, batch_order: str = "shuffled"):
         """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
         each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
         does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
@@ -1014,6 +1028,7 @@ class Trainer:
         self.grad_buckets = int(grad_buckets)  # level groups of the table gradient's reduction, see there
         self.batch_group = int(batch_group)    # batches per launch of the on-device producer (BatchPipeline)
         self.native_steps = bool(native_steps)  # queue steady-state steps with one library call (SteadyLoop)
+        self.batch_order = batch_order  # order of a batch's rows on the device (BatchPipeline: "shuffled" / "morton")
         self.rank, self.world = 0, 1
         if distributed:
             rank, world, _ = parallel.env_world()
@@ -1071,7 +1086,7 @@ class Trainer:
         if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
                 and len(train_dataloaders) > 0:
             train_dataloaders.set_epoch(0)
-            pipe = BatchPipeline(train_dataloaders, group=self.batch_group)
+            pipe = BatchPipeline(train_dataloaders, group=self.batch_group, order=self.batch_order)
             self.fused.forget_ahead()  # a new pipeline: nothing counted earlier is about its batches
         # one library call per step (SteadyLoop, native form) once the first eager steps have set up the
         # steady state -- same launches on the same data, bit-identical parameters

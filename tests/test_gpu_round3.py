@@ -366,13 +366,16 @@ def test_grouped_batch_production_gives_the_same_batches(amd, steps):
 
 # --------------------------------------------------------------------------- hipGraph replays
 @pytest.mark.parametrize("mode", ["native", "graph"])
-@pytest.mark.parametrize("hidden,records", [(128, 0), (64, 0), (128, 1)])
-def test_steady_loop_equals_the_eager_loop(amd, hidden, records, mode):
+@pytest.mark.parametrize("hidden,records,order", [(128, 0, "shuffled"), (64, 0, "shuffled"), (128, 1, "shuffled"),
+                                                  (128, 0, "morton"), (64, 0, "morton")])
+def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
     """trainer.SteadyLoop queues the fused step with ONE library call (`mri_fused_step`, mode native) or replays
     it as one hipGraph per buffer parity (mode graph: Adam's prefactors and the next batch's shuffle position
     read from a device-resident mri_step_params block): after 70 steps over several epochs -- eager steps mixed
     in, as bench.py's event-bracketed sample steps are -- parameters, both Adam moments and the step count
     equal the eager loop's bit for bit."""
+    if mode == "graph" and order == "morton":
+        pytest.skip("ordered batches are queued natively or eagerly (SteadyLoop refuses the graph form)")
     amd.lib.set_option("bwd_records", records)
     dev = torch.device("cuda", 0)
     vol = amd.datamodules.phantom_volume((40, 40, 40), device=dev)
@@ -386,7 +389,7 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, mode):
         if mode == "graph":
             step.count_ahead = True  # (the native form also serves the 64-wide decoder's default: counted in-step)
         loader = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=True, seed=1337)
-        return net, step, amd.datamodules.BatchPipeline(loader)
+        return net, step, amd.datamodules.BatchPipeline(loader, order=order)
 
     n_steps = 70
     _, eager, pipe_e = build()
@@ -449,3 +452,77 @@ def test_trainer_fit_with_native_steps_equals_eager_fit(amd):
     tr = amd.trainer.Trainer(max_epochs=2, log_every=0)
     tr.fit(net, ragged)
     assert tr.global_step == 2 * 11 and bool(torch.isfinite(tr.fused.flat.param).all())
+
+
+# --------------------------------------------------------------------------- the order of a batch's rows
+def _morton_cells(idx, shape, cell):
+    """Cell number (at `cell` voxels per axis) of flat C-order voxel indices."""
+    out, rest = [], idx.clone()
+    for extent in reversed(shape):
+        out.append((rest % extent) // cell)
+        rest = rest // extent
+    key = torch.zeros_like(idx)
+    for c in out:
+        key = key * 4096 + c
+    return key
+
+
+@pytest.mark.parametrize("shape,n", [((256, 256, 256), 1 << 18), ((352, 352, 6, 15), 100_000), ((40, 40, 40), 4096),
+                                     ((64, 48), 1000), ((33, 7, 5), 50)])
+def test_order_batch_is_a_deterministic_permutation(amd, shape, n):
+    """ops.order_batch (mri_order_batch) re-orders the flat voxel indices of a batch: the SET is untouched (the
+    shuffle decides which voxels a batch holds), the order is the same every run, batches shorter than a
+    transposition block and of other dimensions pass, and in a full block a wave's 64 rows come from 64 different
+    neighbourhoods while neighbouring rows of consecutive waves are close (what the kernels want, see the entry
+    point's comment)."""
+    dev = torch.device("cuda", 0)
+    total = 1
+    for e in shape:
+        total *= e
+    g = torch.Generator(device="cpu").manual_seed(5)
+    idx = torch.randperm(total, generator=g)[:n].to(dev)
+    a, b = idx.clone(), idx.clone()
+    amd.ops.order_batch(a, shape)
+    amd.ops.order_batch(b, shape)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), "two runs order the same batch differently"
+    assert torch.equal(torch.sort(a).values, torch.sort(idx).values), "the batch's set changed"
+    if n >= 16384 and len(shape) == 3:
+        assert not torch.equal(a, idx)
+        cells = _morton_cells(a[:16384], shape, 16).reshape(256, 64)  # [wave][lane] of the first block
+        per_wave = torch.tensor([len(torch.unique(cells[w])) for w in range(0, 256, 17)])
+        assert int(per_wave.min()) >= 48, per_wave  # a wave: (almost) as many 16-voxel cells as lanes
+        same = (cells[1:] == cells[:-1]).float().mean()  # lane l of waves w, w + 1: Morton neighbours
+        assert float(same) > 0.8, float(same)
+
+
+def test_ordered_batch_gives_the_same_step(amd):
+    """A fused training step on a batch in Morton order and on the same rows in shuffle order: predictions and
+    the gradient of the encoding are row-wise, the table gradient an exact sum -- bit-identical tables'
+    gradients --, loss and decoder gradients are sums in another order (1e-5 of their largest entry)."""
+    dev = torch.device("cuda", 0)
+    vol = amd.datamodules.phantom_volume((64, 64, 64), device=dev)
+    ds = amd.datamodules.MriImage(volume=vol, device=dev)
+    loader = amd.datamodules.DeviceLoader(ds, 1 << 15, shuffle=True, drop_last=True, seed=11)
+    grads = []
+    for order in ("shuffled", "morton"):
+        torch.manual_seed(1337)
+        net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
+                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
+        with torch.no_grad():
+            net.encoder.table.uniform_(-0.5, 0.5)
+        step = amd.trainer.FusedStep(net, net.configure_optimizers())
+        pipe = amd.datamodules.BatchPipeline(loader, order=order)
+        c, t = pipe.current()
+        loss = float(step.train_step(c, t))  # (the gradients stay in the flat buffer behind the Adam step)
+        torch.cuda.synchronize()
+        grads.append((loss, step.flat.grad.clone(), c.clone()))
+    (l0, g0, c0), (l1, g1, c1) = grads
+    key = lambda c: torch.sort((c * torch.tensor([1.0, 64.0, 4096.0], device=dev)).sum(1).double()).values  # noqa: E731
+    assert not torch.equal(c0, c1) and torch.equal(key(c0), key(c1))
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    diff = (g0 - g1).abs()
+    assert float(diff.max()) <= 1e-5 * float(g0.abs().max())
+    table = step.encoder.table
+    lo = (table.data_ptr() - step.flat.param.data_ptr()) // 4
+    assert torch.equal(g0[lo:lo + table.numel()], g1[lo:lo + table.numel()]), "table gradients differ in bits"

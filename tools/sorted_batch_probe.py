@@ -46,3 +46,24 @@ if "--levels" in sys.argv:
                                                          level_mask=1 << l), reps=20))
         print("  level %2d  res %5d  slots %7d : %.4f / %.4f" % (l, int(enc.desc.resolution[l][0]),
                                                                int(enc.desc.table_size[l]), t[0], t[1]), flush=True)
+if "--split" in sys.argv:  # the dense levels (0-2) and the record levels (3-15) as two calls
+    for name, mask in (("dense levels 0-2 ", 0x7), ("record levels 3-15", 0xFFF8)):
+        t = [timed(lambda: ops.hashgrid_backward(enc.desc, c, d, g, feature_major=True, method=2, overwrite=True,
+                                                 level_mask=mask)) for c in (x, xr, xs)]
+        print("%s: shuffled %.4f  raster %.4f  morton %.4f ms" % (name, *t), flush=True)
+if "--transposed" in sys.argv:
+    # Morton order, then inside blocks of `blk` consecutive coordinates a transposition: a wave's 64 lanes take every
+    # (blk / 64)-th coordinate of the block (64 different neighbourhoods: no equal slots inside a wave), consecutive
+    # waves take their Morton neighbours (the same cache lines a moment later, on the same CU)
+    order = torch.argsort(morton)
+    for blk in (64, 256, 1024, 4096, 16384, 65536):
+        q = torch.arange(n, device="cuda")
+        inner = q % blk
+        w = blk // 64
+        pos = (q - inner) + (inner % w) * 64 + inner // w if w > 0 else q
+        xt = torch.empty_like(x)
+        xt[pos] = x[order]
+        f = timed(lambda: ops.hashgrid_forward(enc.desc, xt, enc.table.data, out=out, feature_major=True))
+        b = timed(lambda: ops.hashgrid_backward(enc.desc, xt, d, g, feature_major=True, method=2, overwrite=True))
+        bd = timed(lambda: ops.hashgrid_backward(enc.desc, xt, d, g, feature_major=True, method=2, overwrite=True, level_mask=0x7))
+        print("morton, transposed in blocks of %6d: lookup %.4f ms   table gradient %.4f ms   (dense levels alone %.4f)" % (blk, f, b, bd), flush=True)
