@@ -512,11 +512,12 @@ int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* 
                      float* coords_out, float* target_out /* may be NULL */, void* stream);
 /* mri_order_batch: reorders the n flat voxel indices of ONE batch in place -- the set is the shuffle's, the
  *   order of a batch's rows is free (reference models.py:61-66: F.mse_loss is a mean over the batch; the table
- *   gradient a sum) -- along a Morton curve over the `dim` axes (8 bits per axis, position / extent), then
- *   transposed inside blocks of 16384 rows: a wave's 64 rows are 64 different neighbourhoods (no two lanes add
+ *   gradient a sum) -- by the 12 highest bits of a Morton key over the `dim` axes (8 bits per axis, position /
+ *   extent; rows of a bucket keep their shuffle order: one stable counting pass), then transposed inside blocks of
+ *   16384 rows: a wave's 64 rows are 64 different neighbourhoods (no two lanes add
  *   into the same table slot, as in a shuffled batch), consecutive waves are Morton neighbours (the lookup finds
  *   their cache lines again: BASELINE config 4 0.099 -> 0.090 ms, the table gradient 0.222 -> 0.214 ms on the
- *   same batch).  Deterministic (stable radix sort: the same indices give the same order every run).
+ *   same batch).  Deterministic (ranks from chunk, wave and lane order: the same indices give the same order every run).
  *   `shape` is a HOST array of length dim; workspace: mri_order_batch_workspace_bytes(n, dim), 256-byte aligned. */
 int64_t mri_order_batch_workspace_bytes(int64_t n, int32_t dim);
 int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,

@@ -10,22 +10,25 @@
 //   * so the sorted rows are TRANSPOSED inside blocks of 16384: a wave takes every 256th row of a block (64
 //     different neighbourhoods: no equal slots inside a wave, as in a shuffled batch), consecutive waves take
 //     their Morton neighbours (the same lines, a moment later, on the same CU).  Measured on the same batch:
-//     lookup 0.099 -> 0.090 ms, table gradient 0.222 -> 0.214 ms (its scatter writes longer runs).
+//     lookup 0.099 -> 0.090 ms, table gradient 0.222 -> 0.214 ms (its scatter writes longer runs);
+//   * the 12 highest bits of the Morton key carry that gain (4096 cells; `--coarse` of the probe: 9 bits 0.0947 /
+//     0.2199 ms, 12 bits 0.0908 / 0.2119, all 24 bits 0.0899 / 0.2107), so the sort is ONE stable counting pass
+//     over 4096 buckets: rows keep their shuffle order inside a bucket.
 //
-// The sort is rocPRIM's radix_sort_pairs (stable, deterministic: the same batch gives the same order every run) on a
-// 16-bit prefix of the Morton key; keys and the permutation live in the caller's workspace.
+// Four launches (count per 1024-row chunk -> per-bucket scan -> bucket bases -> place), deterministic: a row's rank
+// inside its bucket comes from chunk, wave and lane order, never from the order atomics happen in.
 //
 // State at the end of round 3: an OPTION (BatchPipeline(order="morton"), bench.py --batch-order morton), not the
-// default.  With ordered batches every kernel of BASELINE config 4's step is faster under rocprofv3 (lookup 105.1 ->
+// default.  On ordered batches every kernel of BASELINE config 4's step is faster under rocprofv3 (lookup 105.1 ->
 // 96.6 us, scatter 75.6 -> 74.5, dense + accumulate 86.6 -> 82.7, count 60.2 -> 50.7, gather 20.1 -> 10.7) and the
-// step is slower, 0.536 against 0.513 ms: for 2^18 pairs rocPRIM takes its merge-sort path -- one block sort and
-// eight merge passes, 17 launches, ~120 us on the side stream -- which does not fit beside the lookup (indices are
-// therefore produced two batches ahead, mri_fused_step_args::next2_idx) and then runs beside the table gradient,
-// costing it 17 us.  What it needs is a two-pass counting sort of its own (~6 launches).
-#include <cstring>
-
+// step is not: 0.522 against 0.515 ms.  The ordering does not fit beside the lookup, where the rest of the batch
+// production already fills the side stream (indices are therefore produced two batches ahead,
+// mri_fused_step_args::next2_idx), and what runs beside the table gradient instead costs it ~10 us.  Earlier
+// versions: rocprim::radix_sort_pairs takes its merge-sort path for 2^18 pairs (17 launches, ~120 us on the side
+// stream: 0.536 ms; it also loses values when the sorted bit window ends at bit 32 of a 32-bit key,
+// tools/probes/rocprim_sort_probe.hip), a two-pass 8-bit radix sort of six naive launches was slower still
+// (0.59 ms), this pass with its scan in ONE workgroup 0.529 (one CU's ~10 bytes per cycle over a 6 MB table).
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -33,72 +36,171 @@ namespace mri {
 namespace {
 
 constexpr int kBlockRows = 16384;  // rows of a transposition block (a multiple of 64)
+constexpr int kChunk = 1024;       // rows (= threads) of a workgroup of the count and place kernels
+constexpr int kKeyBits = 12;
+constexpr int kBuckets = 1 << kKeyBits;
+constexpr int kWaves = kChunk / 64;
 
 struct OrderShape {
   int64_t shape[MRI_MAX_DIM];
 };
 
-// Up to 8 bits per axis (position / extent, so that axes of different lengths weigh the same), interleaved with
-// the LAST axis in the lowest bit; up to 4 axes (more: the first four decide) in at most 28 bits -- 7 bits per axis
-// for 4 axes: rocPRIM 3.x loses values when the sorted bit window ends at bit 32 of a 32-bit key
-// (tools/probes/rocprim_sort_probe.hip: windows [0, 16), [8, 24) fine, [16, 32): 99,998 of 100,000 values lost).
-__host__ __device__ inline int axes_used(int dim) { return dim < 4 ? dim : 4; }
-__host__ __device__ inline int axis_bits(int dim) { return axes_used(dim) < 4 ? 8 : 7; }
-
-__global__ __launch_bounds__(256) void order_key_kernel(const int64_t* __restrict__ idx, int64_t n, int dim,
-                                                        OrderShape s, uint32_t* __restrict__ key) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int64_t rest = idx[i];
+// Morton key: up to 8 bits per axis (position / extent, so that axes of different lengths weigh the same),
+// interleaved with the LAST axis in the lowest bit; up to 4 axes (more: the first four decide).  The bucket is its
+// kKeyBits highest bits (fewer key bits than that -- one axis: all of them).
+__device__ __forceinline__ uint32_t bucket_of(int64_t flat, int dim, const OrderShape& s, bool small) {
   uint32_t q[MRI_MAX_DIM];
-  const int bits = axis_bits(dim);
-  for (int d = dim - 1; d >= 0; --d) {  // C order: last axis fastest (as mri_gather_batch)
-    const int64_t pos = rest % s.shape[d];
-    rest /= s.shape[d];
-    q[d] = (uint32_t)((pos << bits) / s.shape[d]);
+  if (small) {  // fewer than 2^24 positions per axis and 2^32 voxels: 32-bit divisions (wave-uniform branch)
+    uint32_t rest = (uint32_t)flat;
+    for (int d = dim - 1; d >= 0; --d) {  // C order: last axis fastest (as mri_gather_batch)
+      const uint32_t extent = (uint32_t)s.shape[d], pos = rest % extent;
+      rest /= extent;
+      q[d] = (pos << 8) / extent;
+    }
+  } else {
+    int64_t rest = flat;
+    for (int d = dim - 1; d >= 0; --d) {
+      const int64_t pos = rest % s.shape[d];
+      rest /= s.shape[d];
+      q[d] = (uint32_t)((pos << 8) / s.shape[d]);
+    }
   }
-  const int used = axes_used(dim);
+  const int used = dim < 4 ? dim : 4;
   uint32_t k = 0;
-  for (int b = bits - 1; b >= 0; --b)
+  for (int b = 7; b >= 0; --b)
     for (int d = 0; d < used; ++d) k = (k << 1) | ((q[d] >> b) & 1u);
-  key[i] = k;
+  const int bits = 8 * used;
+  return bits > kKeyBits ? k >> (bits - kKeyBits) : k;
 }
 
-// sorted row q -> position: inside full blocks of kBlockRows the transposition, the tail as it is
-__global__ __launch_bounds__(256) void order_place_kernel(const int64_t* __restrict__ sorted, int64_t n,
-                                                          int64_t* __restrict__ idx) {
-  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (q >= n) return;
+// 1. per chunk of 1024 rows: every row's bucket and its rank among the chunk's rows of the same bucket (in row
+//    order), the chunk's count per bucket, and a copy of the indices (the place kernel writes `idx` in place)
+__global__ __launch_bounds__(kChunk) void order_count_kernel(const int64_t* __restrict__ idx, int64_t n, int dim,
+                                                             OrderShape s, int small, int64_t* __restrict__ idx_copy,
+                                                             uint16_t* __restrict__ bucket, uint16_t* __restrict__ rank,
+                                                             uint16_t* __restrict__ chunk_count) {
+  __shared__ uint8_t wave_cnt[kWaves][kBuckets];  // rows of each wave per bucket (<= 64)
+  {
+    uint4* z = reinterpret_cast<uint4*>(&wave_cnt[0][0]);
+    for (int e = threadIdx.x; e < kWaves * kBuckets / 16; e += kChunk) z[e] = uint4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kChunk + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = i < n;
+  uint32_t b = 0;
+  if (live) {
+    const int64_t v = idx[i];
+    idx_copy[i] = v;
+    b = bucket_of(v, dim, s, small != 0);
+  }
+  unsigned long long peers = __ballot(live);  // lanes of this wave in the same bucket: one ballot per key bit
+#pragma unroll
+  for (int k = 0; k < kKeyBits; ++k) {
+    const unsigned long long set = __ballot(live && ((b >> k) & 1u));
+    peers &= ((b >> k) & 1u) ? set : ~set;
+  }
+  const int in_wave = __popcll(peers & ((1ull << lane) - 1ull));
+  if (live && in_wave == 0) wave_cnt[wave][b] = (uint8_t)__popcll(peers);
+  __syncthreads();
+  if (live) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w][b];
+    bucket[i] = (uint16_t)b;
+    rank[i] = (uint16_t)(before + in_wave);
+  }
+  uint16_t* __restrict__ row = chunk_count + (int64_t)blockIdx.x * kBuckets;
+  for (int e = threadIdx.x; e < kBuckets; e += kChunk) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) c += wave_cnt[w][e];
+    row[e] = (uint16_t)c;
+  }
+}
+
+// 2a. per bucket the exclusive prefix of its counts over the chunks (chunk order = row order) and its total: one
+//     thread per bucket, 64-thread workgroups (a single workgroup walking the whole 6 MB table is bound by ONE CU's
+//     ~10 bytes per cycle: 100 us)
+__global__ __launch_bounds__(64) void order_scan_kernel(const uint16_t* __restrict__ chunk_count, int chunks,
+                                                        uint32_t* __restrict__ chunk_prefix,
+                                                        uint32_t* __restrict__ bucket_total) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  uint32_t run = 0;
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {  // eight loads in flight
+    uint16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = chunk_count[(int64_t)(c + j) * kBuckets + b];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      chunk_prefix[(int64_t)(c + j) * kBuckets + b] = run;
+      run += v[j];
+    }
+  }
+  for (; c < chunks; ++c) {
+    const uint32_t v = chunk_count[(int64_t)c * kBuckets + b];
+    chunk_prefix[(int64_t)c * kBuckets + b] = run;
+    run += v;
+  }
+  bucket_total[b] = run;
+}
+
+// 2b. the buckets' bases: exclusive scan of the 4096 totals, one workgroup, four buckets per thread
+__global__ __launch_bounds__(1024) void order_base_kernel(const uint32_t* __restrict__ bucket_total,
+                                                          uint32_t* __restrict__ bucket_base) {
+  __shared__ uint32_t part[1024];
+  static_assert(kBuckets == 4096, "four buckets per thread");
+  const uint4 t = reinterpret_cast<const uint4*>(bucket_total)[threadIdx.x];
+  part[threadIdx.x] = t.x + t.y + t.z + t.w;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of the 1024 sums
+    const uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t base = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+  reinterpret_cast<uint4*>(bucket_base)[threadIdx.x] = uint4{base, base + t.x, base + t.x + t.y, base + t.x + t.y + t.z};
+}
+
+// 3. sorted position = bucket base + rows of the bucket in earlier chunks + rank inside the chunk; inside full
+//    blocks of kBlockRows the transposition, the tail as it is
+__global__ __launch_bounds__(kChunk) void order_place_kernel(const int64_t* __restrict__ idx_copy, int64_t n,
+                                                             const uint16_t* __restrict__ bucket,
+                                                             const uint16_t* __restrict__ rank,
+                                                             const uint32_t* __restrict__ chunk_prefix,
+                                                             const uint32_t* __restrict__ bucket_base,
+                                                             int64_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * kChunk + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t b = bucket[i];
+  const int64_t q = (int64_t)bucket_base[b] + chunk_prefix[(int64_t)blockIdx.x * kBuckets + b] + rank[i];
   const int64_t inner = q % kBlockRows, base = q - inner;
   constexpr int w = kBlockRows / 64;
-  const int64_t pos = base + kBlockRows <= n ? base + (inner % w) * 64 + inner / w : q;
-  idx[pos] = sorted[q];
+  idx[base + kBlockRows <= n ? base + (inner % w) * 64 + inner / w : q] = idx_copy[i];
 }
 
 struct OrderWs {
-  uint32_t *key_in, *key_out;
-  int64_t* val_out;
-  void* temp;
-  size_t temp_bytes;
+  int64_t* idx_copy;
+  uint16_t *bucket, *rank, *chunk_count;
+  uint32_t *chunk_prefix, *bucket_total, *bucket_base;
   int64_t total;
 };
 
-int key_bits(int dim) { return axis_bits(dim) * axes_used(dim); }
-
-OrderWs carve_order(void* base, int64_t n, int dim) {
+OrderWs carve_order(void* base, int64_t n) {
   OrderWs w{};
-  size_t temp = 0;
-  const int end = key_bits(dim), begin = end > 16 ? end - 16 : 0;
-  (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)n, begin, end, (hipStream_t)0);
-  const int64_t keys = (n * 4 + 255) / 256 * 256;
+  const int64_t chunks = ceil_div(n, kChunk);
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
   char* p = static_cast<char*>(base);
-  w.key_in = reinterpret_cast<uint32_t*>(p);
-  w.key_out = reinterpret_cast<uint32_t*>(p + keys);
-  w.val_out = reinterpret_cast<int64_t*>(p + 2 * keys);
-  w.temp = p + 2 * keys + (n * 8 + 255) / 256 * 256;
-  w.temp_bytes = temp;
-  w.total = 2 * keys + (n * 8 + 255) / 256 * 256 + (int64_t)temp + 256;
+  int64_t off = 0;
+  w.idx_copy = reinterpret_cast<int64_t*>(p + off), off += up(n * 8);
+  w.bucket = reinterpret_cast<uint16_t*>(p + off), off += up(n * 2);
+  w.rank = reinterpret_cast<uint16_t*>(p + off), off += up(n * 2);
+  w.chunk_count = reinterpret_cast<uint16_t*>(p + off), off += up(chunks * kBuckets * 2);
+  w.chunk_prefix = reinterpret_cast<uint32_t*>(p + off), off += up(chunks * kBuckets * 4);
+  w.bucket_total = reinterpret_cast<uint32_t*>(p + off), off += up(kBuckets * 4);
+  w.bucket_base = reinterpret_cast<uint32_t*>(p + off), off += up(kBuckets * 4);
+  w.total = off;
   return w;
 }
 
@@ -108,8 +210,8 @@ OrderWs carve_order(void* base, int64_t n, int dim) {
 using namespace mri;
 
 extern "C" int64_t mri_order_batch_workspace_bytes(int64_t n, int32_t dim) {
-  if (n < 1 || dim < 1 || dim > MRI_MAX_DIM) return -1;
-  return carve_order(nullptr, n, dim).total;
+  if (n < 1 || n >= (1ll << 31) || dim < 1 || dim > MRI_MAX_DIM) return -1;
+  return carve_order(nullptr, n).total;
 }
 
 extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,
@@ -118,7 +220,7 @@ extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64
   if (n < 2) return MRI_OK;
   MRI_REQUIRE(idx && shape && workspace, "NULL pointer");
   MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
-  const OrderWs w = carve_order(workspace, n, dim);
+  const OrderWs w = carve_order(workspace, n);
   MRI_REQUIRE(workspace_bytes >= w.total, "mri_order_batch needs a workspace of %lld bytes (mri_order_batch_workspace_bytes)",
               (long long)w.total);
   OrderShape s{};
@@ -127,13 +229,21 @@ extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64
     s.shape[d] = shape[d];
   }
   hipStream_t st = (hipStream_t)stream;
-  const unsigned blocks = (unsigned)ceil_div(n, 256);
-  hipLaunchKernelGGL(order_key_kernel, dim3(blocks), dim3(256), 0, st, idx, n, (int)dim, s, w.key_in);
-  const int end = key_bits(dim), begin = end > 16 ? end - 16 : 0;
-  size_t temp = w.temp_bytes;
-  if (rocprim::radix_sort_pairs(w.temp, temp, w.key_in, w.key_out, (const int64_t*)idx, w.val_out, (size_t)n, begin, end,
-                                st) != hipSuccess)
-    return fail(MRI_ERR_LAUNCH, "mri_order_batch: radix sort");
-  hipLaunchKernelGGL(order_place_kernel, dim3(blocks), dim3(256), 0, st, w.val_out, n, idx);
-  return check_launch("order_place_kernel");
+  const int chunks = (int)ceil_div(n, kChunk);
+  int small = 1;  // 32-bit index arithmetic on the device where it is exact
+  double voxels = 1.0;
+  for (int d = 0; d < dim; ++d) {
+    voxels *= (double)shape[d];
+    if (shape[d] >= (1ll << 24)) small = 0;
+  }
+  if (voxels >= 4294967296.0) small = 0;
+  hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)chunks), dim3(kChunk), 0, st, (const int64_t*)idx, n, (int)dim, s,
+                     small, w.idx_copy, w.bucket, w.rank, w.chunk_count);
+  hipLaunchKernelGGL(order_scan_kernel, dim3(kBuckets / 64), dim3(64), 0, st, (const uint16_t*)w.chunk_count, chunks,
+                     w.chunk_prefix, w.bucket_total);
+  hipLaunchKernelGGL(order_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)w.bucket_total, w.bucket_base);
+  hipLaunchKernelGGL(order_place_kernel, dim3((unsigned)chunks), dim3(kChunk), 0, st, (const int64_t*)w.idx_copy, n,
+                     (const uint16_t*)w.bucket, (const uint16_t*)w.rank, (const uint32_t*)w.chunk_prefix,
+                     (const uint32_t*)w.bucket_base, idx);
+  return check_launch("mri_order_batch");
 }

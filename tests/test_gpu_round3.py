@@ -487,6 +487,28 @@ def test_order_batch_is_a_deterministic_permutation(amd, shape, n):
     torch.cuda.synchronize()
     assert torch.equal(a, b), "two runs order the same batch differently"
     assert torch.equal(torch.sort(a).values, torch.sort(idx).values), "the batch's set changed"
+    # the documented order, restated: stable sort on the 12 highest bits of the Morton key (8 bits per axis, last axis
+    # in the lowest bit, at most four axes), then the transposition inside full blocks of 16384 rows
+    used = min(len(shape), 4)
+    pos, rest = [], idx.clone()
+    for extent in reversed(shape):
+        pos.append(((rest % extent) * 256) // extent)
+        rest = rest // extent
+    pos = pos[::-1][:used]
+    key = torch.zeros_like(idx)
+    for bit in range(7, -1, -1):
+        for d in range(used):
+            key = key * 2 + ((pos[d] >> bit) & 1)
+    if 8 * used > 12:
+        key = key >> (8 * used - 12)
+    ordered = idx[torch.sort(key, stable=True).indices]
+    q = torch.arange(n, device=dev)
+    inner = q % 16384
+    full = (q - inner + 16384) <= n
+    place = torch.where(full, q - inner + (inner % 256) * 64 + inner // 256, q)
+    want = torch.empty_like(ordered)
+    want[place] = ordered
+    assert torch.equal(a, want), "not the documented order"
     if n >= 16384 and len(shape) == 3:
         assert not torch.equal(a, idx)
         cells = _morton_cells(a[:16384], shape, 16).reshape(256, 64)  # [wave][lane] of the first block

@@ -67,3 +67,16 @@ if "--transposed" in sys.argv:
         b = timed(lambda: ops.hashgrid_backward(enc.desc, xt, d, g, feature_major=True, method=2, overwrite=True))
         bd = timed(lambda: ops.hashgrid_backward(enc.desc, xt, d, g, feature_major=True, method=2, overwrite=True, level_mask=0x7))
         print("morton, transposed in blocks of %6d: lookup %.4f ms   table gradient %.4f ms   (dense levels alone %.4f)" % (blk, f, b, bd), flush=True)
+if "--coarse" in sys.argv:
+    # how many key bits does the lookup's gain need?  stable sort on the top `bits` bits of the 24-bit Morton key,
+    # then the transposition in blocks of 16384
+    for bits in (9, 12, 15, 18, 24):
+        order = torch.sort(morton >> (24 - bits), stable=True).indices
+        q = torch.arange(n, device="cuda")
+        inner = q % 16384
+        pos = (q - inner) + (inner % 256) * 64 + inner // 256
+        xt = torch.empty_like(x)
+        xt[pos] = x[order]
+        f = timed(lambda: ops.hashgrid_forward(enc.desc, xt, enc.table.data, out=out, feature_major=True))
+        b = timed(lambda: ops.hashgrid_backward(enc.desc, xt, d, g, feature_major=True, method=2, overwrite=True))
+        print("top %2d key bits, transposed: lookup %.4f ms   table gradient %.4f ms" % (bits, f, b), flush=True)
