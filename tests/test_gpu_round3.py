@@ -365,17 +365,16 @@ def test_grouped_batch_production_gives_the_same_batches(amd, steps):
 
 
 # --------------------------------------------------------------------------- hipGraph replays
-@pytest.mark.parametrize("mode", ["native", "graph"])
-@pytest.mark.parametrize("hidden,records,order", [(128, 0, "shuffled"), (64, 0, "shuffled"), (128, 1, "shuffled"),
-                                                  (128, 0, "morton"), (64, 0, "morton")])
+@pytest.mark.parametrize("hidden,records,order,mode", [
+    (128, 0, "shuffled", "native"), (64, 0, "shuffled", "native"), (128, 1, "shuffled", "native"),
+    (128, 0, "shuffled", "graph"), (64, 0, "shuffled", "graph"), (128, 1, "shuffled", "graph"),
+    (128, 0, "morton", "native"), (64, 0, "morton", "native")])  # (ordered batches: native or eager, never graph replays)
 def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
     """trainer.SteadyLoop queues the fused step with ONE library call (`mri_fused_step`, mode native) or replays
     it as one hipGraph per buffer parity (mode graph: Adam's prefactors and the next batch's shuffle position
     read from a device-resident mri_step_params block): after 70 steps over several epochs -- eager steps mixed
     in, as bench.py's event-bracketed sample steps are -- parameters, both Adam moments and the step count
     equal the eager loop's bit for bit."""
-    if mode == "graph" and order == "morton":
-        pytest.skip("ordered batches are queued natively or eagerly (SteadyLoop refuses the graph form)")
     amd.lib.set_option("bwd_records", records)
     dev = torch.device("cuda", 0)
     vol = amd.datamodules.phantom_volume((40, 40, 40), device=dev)
@@ -424,6 +423,9 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
     assert amd.trainer.SteadyLoop.unsupported(st2, pipe2) is None
     short = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=False, seed=1)
     assert "full" in amd.trainer.SteadyLoop.unsupported(st, amd.datamodules.BatchPipeline(short))
+    if order == "morton":
+        with pytest.raises(ValueError, match="graph"):
+            amd.trainer.SteadyLoop(st2, pipe2, mode="graph")
 
 
 def test_trainer_fit_with_native_steps_equals_eager_fit(amd):
