@@ -294,8 +294,8 @@ def main():
                          "it): 'shuffled' leaves them as the permutation yields them; 'morton' re-orders them on the "
                          "device along a Morton curve, transposed inside blocks of 16384 rows (mri_order_batch) -- every "
                          "kernel of the step then runs faster (lookup -8 us, scatter + accumulate -5 us) and the step "
-                         "does not, 0.522 against 0.515 ms: the ordering finds no room beside the lookup and runs beside "
-                         "the table gradient (DESIGN.md 8)")
+                         "does not, 0.535 against 0.512 ms: 32 us of ordering per step have nowhere to hide "
+                         "(DESIGN.md 8)")
     ap.add_argument("--cold-start", action="store_true",
                     help="time the first leg on a device that has just left idle (the order until round 3: timed legs, "
                          "then the quality leg); by default the quality leg's training steps run first, so that every "

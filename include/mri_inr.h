@@ -479,16 +479,8 @@ typedef struct mri_fused_step_args {
                                                     parallel: the world size, with n_params = 0 -- the caller
                                                     reduces `grad` over the ranks and steps (mri_adam_step) */
   float reserved2;
-  /* Batches in spatial order (mri_order_batch), or order_ws = NULL: shuffle order.  The sort takes longer than the
-   * lookup it would have to hide behind, so indices are produced TWO batches ahead: `next_idx` then already holds the
-   * ordered indices of the next batch (the previous call left them there) and is only gathered; the indices of the
-   * batch after it -- mri_sample_indices(seed2, first2, lo, hi, next_n) -> mri_order_batch -- go to `next2_idx` at the
-   * END of the side stream's work, behind the event the next call waits for. */
-  void* order_ws;
-  int64_t order_ws_bytes;
-  int64_t* next2_idx;
-  uint64_t seed2;
-  int64_t first2;
+  void* order_ws;                                /* the next batch in spatial order (mri_order_gather_batch in place of */
+  int64_t order_ws_bytes;                        /* mri_gather_batch), or NULL: shuffle order */
 } mri_fused_step_args;
 int mri_fused_step(const mri_fused_step_args* args);
 int64_t mri_fused_step_args_bytes(void); /* sizeof(mri_fused_step_args): lets a binding check its layout */
@@ -522,6 +514,12 @@ int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* 
 int64_t mri_order_batch_workspace_bytes(int64_t n, int32_t dim);
 int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,
                     int64_t workspace_bytes, void* stream);
+/* mri_order_batch followed by mri_gather_batch on the ordered indices, with the gather done by the ordering's last
+ *   launch (same indices, coordinates and targets). */
+int mri_order_gather_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, const float* axes,
+                           const int64_t* axis_offset, const float* volume, float* coords_out,
+                           float* target_out /* may be NULL */, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,8 +61,7 @@ class FusedStepArgs(C.Structure):
            ("volume", C.c_void_p)]
         + [(k, C.c_void_p) for k in ("stream", "stream_side", "ev_fork", "ev_join")]
         + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float),
-           ("order_ws", C.c_void_p), ("order_ws_bytes", C.c_int64), ("next2_idx", C.c_void_p),
-           ("seed2", C.c_uint64), ("first2", C.c_int64)])
+           ("order_ws", C.c_void_p), ("order_ws_bytes", C.c_int64)])
 
 
 _P = C.c_void_p
@@ -125,6 +124,7 @@ SIGNATURES = {
     "mri_sample_indices_dev": [_P, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
     "mri_order_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, _I64, _P],
+    "mri_order_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P, _I64, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],

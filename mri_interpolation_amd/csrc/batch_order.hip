@@ -21,13 +21,16 @@
 // State at the end of round 3: an OPTION (BatchPipeline(order="morton"), bench.py --batch-order morton), not the
 // default.  On ordered batches every kernel of BASELINE config 4's step is faster under rocprofv3 (lookup 105.1 ->
 // 96.6 us, scatter 75.6 -> 74.5, dense + accumulate 86.6 -> 82.7, count 60.2 -> 50.7, gather 20.1 -> 10.7) and the
-// step is not: 0.522 against 0.515 ms.  The ordering does not fit beside the lookup, where the rest of the batch
-// production already fills the side stream (indices are therefore produced two batches ahead,
-// mri_fused_step_args::next2_idx), and what runs beside the table gradient instead costs it ~10 us.  Earlier
-// versions: rocprim::radix_sort_pairs takes its merge-sort path for 2^18 pairs (17 launches, ~120 us on the side
-// stream: 0.536 ms; it also loses values when the sorted bit window ends at bit 32 of a 32-bit key,
-// tools/probes/rocprim_sort_probe.hip), a two-pass 8-bit radix sort of six naive launches was slower still
-// (0.59 ms), this pass with its scan in ONE workgroup 0.529 (one CU's ~10 bytes per cycle over a 6 MB table).
+// step is not: the ordering is 32 us of GPU work per step (this file, alone on the GPU) that has nowhere to hide.
+// Beside the lookup -- whose workgroups hold every wave slot, so that a side kernel gets CU time only as they retire --
+// the four launches stretch to ~280 us, the counting stage of the table gradient lands behind the decoder and beside
+// the scatter: 0.535 against 0.512 ms (the lookup itself, alone at last: 0.0965 instead of 0.108 ms).  Produced two
+// batches ahead, behind everything the next step waits for, the ordering ran beside the table gradient: 0.522
+// against 0.515 (that form is in the history, commit "one stable counting pass").  Earlier sorts:
+// rocprim::radix_sort_pairs takes its merge-sort path for 2^18 pairs (17 launches, ~120 us: 0.536 ms; it also loses
+// values when the sorted bit window ends at bit 32 of a 32-bit key, tools/probes/rocprim_sort_probe.hip), a two-pass
+// 8-bit radix sort of six naive launches (0.59 ms), this pass with its scan in ONE workgroup (0.529: one CU's ~10
+// bytes per cycle over a 6 MB table).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -43,6 +46,7 @@ constexpr int kWaves = kChunk / 64;
 
 struct OrderShape {
   int64_t shape[MRI_MAX_DIM];
+  int64_t axis_offset[MRI_MAX_DIM];  // (the gathering form: start of axis d in `axes`)
 };
 
 // Morton key: up to 8 bits per axis (position / extent, so that axes of different lengths weigh the same),
@@ -165,19 +169,35 @@ __global__ __launch_bounds__(1024) void order_base_kernel(const uint32_t* __rest
 
 // 3. sorted position = bucket base + rows of the bucket in earlier chunks + rank inside the chunk; inside full
 //    blocks of kBlockRows the transposition, the tail as it is
+//    With `coords` the row is gathered on the spot (what mri_gather_batch would do with the ordered indices: the
+//    same coordinates and targets, one launch less on a side stream that has none to spare).
 __global__ __launch_bounds__(kChunk) void order_place_kernel(const int64_t* __restrict__ idx_copy, int64_t n,
                                                              const uint16_t* __restrict__ bucket,
                                                              const uint16_t* __restrict__ rank,
                                                              const uint32_t* __restrict__ chunk_prefix,
                                                              const uint32_t* __restrict__ bucket_base,
-                                                             int64_t* __restrict__ idx) {
+                                                             int64_t* __restrict__ idx, int dim, OrderShape s,
+                                                             const float* __restrict__ axes,
+                                                             const float* __restrict__ volume,
+                                                             float* __restrict__ coords, float* __restrict__ target) {
   const int64_t i = (int64_t)blockIdx.x * kChunk + threadIdx.x;
   if (i >= n) return;
   const uint32_t b = bucket[i];
   const int64_t q = (int64_t)bucket_base[b] + chunk_prefix[(int64_t)blockIdx.x * kBuckets + b] + rank[i];
   const int64_t inner = q % kBlockRows, base = q - inner;
   constexpr int w = kBlockRows / 64;
-  idx[base + kBlockRows <= n ? base + (inner % w) * 64 + inner / w : q] = idx_copy[i];
+  const int64_t pos = base + kBlockRows <= n ? base + (inner % w) * 64 + inner / w : q;
+  const int64_t flat = idx_copy[i];
+  idx[pos] = flat;
+  if (coords) {
+    if (target) target[pos] = volume[flat];
+    int64_t rest = flat;
+    for (int d = dim - 1; d >= 0; --d) {  // C order: last axis fastest (datamodules.py:162-163), as mri_gather_batch
+      const int64_t at = rest % s.shape[d];
+      rest /= s.shape[d];
+      coords[pos * dim + d] = axes[s.axis_offset[d] + at];
+    }
+  }
 }
 
 struct OrderWs {
@@ -214,11 +234,15 @@ extern "C" int64_t mri_order_batch_workspace_bytes(int64_t n, int32_t dim) {
   return carve_order(nullptr, n).total;
 }
 
-extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+namespace {
+int order_impl(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, const float* axes, const int64_t* axis_offset,
+               const float* volume, float* coords_out, float* target_out, void* workspace, int64_t workspace_bytes,
+               void* stream) {
   MRI_REQUIRE(n >= 0 && n < (1ll << 31) && dim >= 1 && dim <= MRI_MAX_DIM, "bad n / dim");
-  if (n < 2) return MRI_OK;
+  if (n == 0) return MRI_OK;
   MRI_REQUIRE(idx && shape && workspace, "NULL pointer");
+  MRI_REQUIRE(!coords_out || (axes && axis_offset), "coords_out needs the axis tables");
+  MRI_REQUIRE(!target_out || (volume && coords_out), "target_out needs a volume (and coords_out)");
   MRI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
   const OrderWs w = carve_order(workspace, n);
   MRI_REQUIRE(workspace_bytes >= w.total, "mri_order_batch needs a workspace of %lld bytes (mri_order_batch_workspace_bytes)",
@@ -227,6 +251,7 @@ extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64
   for (int d = 0; d < dim; ++d) {
     MRI_REQUIRE(shape[d] >= 1, "shape[%d] < 1", d);
     s.shape[d] = shape[d];
+    s.axis_offset[d] = axis_offset ? axis_offset[d] : 0;
   }
   hipStream_t st = (hipStream_t)stream;
   const int chunks = (int)ceil_div(n, kChunk);
@@ -244,6 +269,20 @@ extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64
   hipLaunchKernelGGL(order_base_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)w.bucket_total, w.bucket_base);
   hipLaunchKernelGGL(order_place_kernel, dim3((unsigned)chunks), dim3(kChunk), 0, st, (const int64_t*)w.idx_copy, n,
                      (const uint16_t*)w.bucket, (const uint16_t*)w.rank, (const uint32_t*)w.chunk_prefix,
-                     (const uint32_t*)w.bucket_base, idx);
+                     (const uint32_t*)w.bucket_base, idx, (int)dim, s, axes, volume, coords_out, target_out);
   return check_launch("mri_order_batch");
+}
+}  // namespace
+
+extern "C" int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  return order_impl(idx, n, dim, shape, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mri_order_gather_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, const float* axes,
+                                      const int64_t* axis_offset, const float* volume, float* coords_out,
+                                      float* target_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  MRI_REQUIRE(coords_out != nullptr, "NULL coords_out");
+  return order_impl(idx, n, dim, shape, axes, axis_offset, volume, coords_out, target_out, workspace, workspace_bytes,
+                    stream);
 }

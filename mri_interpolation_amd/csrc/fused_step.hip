@@ -64,15 +64,16 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
     if ((rc = mri_hashgrid_backward_prepare(g, a->coords, n, a->bwd_method, a->bwd_ws, a->bwd_ws_bytes, side)))
       return rc;
   }
-  MRI_REQUIRE(!a->order_ws || (a->next_idx && a->next2_idx), "fused step: ordered batches need next_idx and next2_idx");
   if (a->next_idx) {  // next batch: sample + gather, zero its absmax buffer, count its records
-    // (ordered batches: its indices were sampled and ordered by the previous call, see the end of this one)
-    if (!a->order_ws && (rc = mri_sample_indices(a->seed, a->first, a->lo, a->hi, a->next_n, a->next_idx, side)))
-      return rc;
+    if ((rc = mri_sample_indices(a->seed, a->first, a->lo, a->hi, a->next_n, a->next_idx, side))) return rc;
     TRACE(1)
-    if ((rc = mri_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
-                               a->next_coords, a->next_target, side)))
-      return rc;
+    if (a->order_ws)  // its rows in spatial order (the set is the shuffle's), gathered by the ordering's last launch
+      rc = mri_order_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
+                                  a->next_coords, a->next_target, a->order_ws, a->order_ws_bytes, side);
+    else
+      rc = mri_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
+                            a->next_coords, a->next_target, side);
+    if (rc) return rc;
     TRACE(2)
     if (a->next_absmax && hipMemsetAsync(a->next_absmax, 0, 32 * sizeof(float), side) != hipSuccess)
       return fail(MRI_ERR_LAUNCH, "fused step: memset");
@@ -123,10 +124,5 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
   // the side work is joined by the NEXT call (join_pending = 1), or by the caller through `ev_join`
   if (hipEventRecord(join, side) != hipSuccess) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(join)");
   TRACE(9)
-  if (a->order_ws) {  // the indices of the batch AFTER the next one, behind everything the next step waits for
-    if ((rc = mri_sample_indices(a->seed2, a->first2, a->lo, a->hi, a->next_n, a->next2_idx, side))) return rc;
-    if ((rc = mri_order_batch(a->next2_idx, a->next_n, a->dim, a->shape, a->order_ws, a->order_ws_bytes, side)))
-      return rc;
-  }
   return MRI_OK;
 }

@@ -243,10 +243,6 @@ class BatchPipeline:
             raise ValueError("BatchPipeline: order='morton' produces batch by batch (group = 1)")
         dev, bs = loader.ds.device, loader.batch_size
         self._order_ws = ops.order_batch_workspace(bs, loader.ds.dim_in, dev) if self.order == "morton" else None
-        # order "morton": the sort takes longer than the lookup the production hides behind, so a batch's INDICES are
-        # sampled and ordered two batches ahead (produce_late: behind everything the next step waits for) and only
-        # gathered one batch ahead (produce_next); _idx_made[slot] = the batch whose indices the slot's buffer holds
-        self._idx_made = [-1, -1]
         rows = bs * self.group
         self.slots = [(torch.empty(rows, dtype=torch.int64, device=dev),
                        torch.empty(rows, loader.ds.dim_in, device=dev),
@@ -260,8 +256,6 @@ class BatchPipeline:
         self._made = [-1, -1]  # group number each buffer holds
         self._due = None
         self._produce_group(0)  # on the current stream
-        if self.order == "morton":
-            self._produce_indices(1)
 
     def _locate(self, k: int):
         """batch k -> (group number, epoch, first batch of the group in its epoch, batches in the group,
@@ -271,15 +265,6 @@ class BatchPipeline:
         b0 = j * self.group
         return e * self.groups_per_epoch + j, self.epoch0 + e, b0, min(self.group, self.per_epoch - b0), b - b0
 
-    def _produce_indices(self, b: int):
-        """order 'morton' (group = 1): the ordered indices of batch b into its slot's index buffer."""
-        e, j = divmod(b, self.per_epoch)
-        first, rows = self.loader.span(j)
-        idx = self.slots[b % 2][0]
-        self.loader.indices(first, rows, self.epoch0 + e, out=idx[:rows])
-        ops.order_batch(idx[:rows], self.loader.ds.shape, self._order_ws)
-        self._idx_made[b % 2] = b
-
     def _produce_group(self, g: int):
         e, j = divmod(g, self.groups_per_epoch)
         b0 = j * self.group
@@ -287,12 +272,13 @@ class BatchPipeline:
         first, _ = self.loader.span(b0)
         total = sum(self.loader.span(b0 + r)[1] for r in range(count))  # only an epoch's last batch is short
         idx, coords, target = self.slots[g % 2]
-        if self.order == "morton":  # (group = 1: g is the batch) indices from produce_late, two batches ahead -- or now
-            if self._idx_made[g % 2] != g:
-                self._produce_indices(g)
+        self.loader.indices(first, total, self.epoch0 + e, out=idx[:total])
+        ds = self.loader.ds
+        if self.order == "morton":  # (group = 1) rows in spatial order, gathered by the ordering's last launch
+            ops.order_gather_batch(idx[:total], ds.shape, ds.axes, ds.axis_offset, ds.pixels, coords[:total],
+                                   target[:total], ws=self._order_ws)
         else:
-            self.loader.indices(first, total, self.epoch0 + e, out=idx[:total])
-        self.loader.ds.batch(idx[:total], coords[:total], target[:total])
+            ds.batch(idx[:total], coords[:total], target[:total])
         self._made[g % 2] = g
 
     def _view(self, k: int):
@@ -320,19 +306,14 @@ class BatchPipeline:
             self._produce_group(g_next)  # batch k+1 does not exist yet (group = 1; one-batch groups)
         elif r == 0 and g_next == g and self._made[(g + 1) % 2] != g + 1:
             self._due = g + 1            # first of several steps on this group: the next one, late
-        if self.order == "morton" and self._idx_made[self.k % 2] != self.k + 2:
-            self._due = self.k + 2       # the indices of the batch after the next: late (its slot's buffer is free:
-        return self._view(self.k + 1)[0]  # batch k was gathered from it a step ago)
+        return self._view(self.k + 1)[0]
 
     def produce_late(self):
         """The deferred production of the next group, to be queued BEHIND whatever the step needs soon
         (FusedStep: behind the count of the next batch's records): its kernels are `group` times longer."""
         if self._due is not None:
             g, self._due = self._due, None
-            if self.order == "morton":
-                self._produce_indices(g)
-            else:
-                self._produce_group(g)
+            self._produce_group(g)
 
     def advance(self):
         self.k += 1

@@ -772,6 +772,27 @@ def order_batch(idx: torch.Tensor, shape: Sequence[int], ws: Optional[torch.Tens
     return idx
 
 
+def order_gather_batch(idx: torch.Tensor, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],
+                       volume: Optional[torch.Tensor], coords=None, target=None, ws: Optional[torch.Tensor] = None):
+    """order_batch(idx) followed by gather_batch on the ordered indices, the gather done by the ordering's last launch
+    (mri_order_gather_batch): same indices, coordinates and targets."""
+    _gpu(idx, axes, volume, coords, target)
+    if idx.dtype != torch.int64 or not idx.is_contiguous():
+        raise ValueError("order_gather_batch: contiguous int64 indices")
+    n, dim = idx.numel(), len(shape)
+    if coords is None:
+        coords = torch.empty((n, dim), device=idx.device, dtype=torch.float32)
+    if target is None and volume is not None:
+        target = torch.empty((n, 1), device=idx.device, dtype=torch.float32)
+    if ws is None:
+        ws = order_batch_workspace(n, dim, idx.device)
+    shp = (C.c_int64 * dim)(*[int(s) for s in shape])
+    off = (C.c_int64 * dim)(*[int(o) for o in axis_offset])
+    _lib.call("mri_order_gather_batch", _ptr(idx), n, dim, shp, _ptr(axes), off, _ptr(volume), _ptr(coords), _ptr(target),
+              _ptr(ws), ws.numel() * 8, _stream())
+    return coords, target
+
+
 def gather_batch(idx, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],
                  volume: Optional[torch.Tensor], coords=None, target=None):
     _gpu(idx, axes, volume, coords, target)

@@ -850,9 +850,8 @@ class SteadyLoop:
         for d in range(ds.dim_in):
             a.shape[d], a.axis_offset[d] = int(ds.shape[d]), int(ds.axis_offset[d])
         a.axes, a.volume = ptr(ds.axes), ptr(ds.pixels)
-        if self.pipe.order == "morton":  # batches in spatial order (ops.order_batch): indices two batches ahead
+        if self.pipe.order == "morton":  # the next batch's rows in spatial order (ops.order_gather_batch)
             a.order_ws, a.order_ws_bytes = ptr(self.pipe._order_ws), self.pipe._order_ws.numel() * 8
-            a.next2_idx = ptr(self.pipe.slots[p][0][:n])  # batch k+2's slot: batch k was gathered from it a step ago
         a.stream_side = st._side.cuda_stream
         a.ev_fork, a.ev_join = self._ev_fork.cuda_event, self._ev_join.cuda_event
         self._keep = getattr(self, "_keep", []) + [tiny_ws]  # (the struct holds raw pointers only)
@@ -929,11 +928,6 @@ class SteadyLoop:
         # what changes per step: Adam's step number, the shuffle position of the NEXT batch
         e, b = divmod(k + 1, pipe.per_epoch)
         seed, first = ld.seed + 7919 * (pipe.epoch0 + e), ld.span(b)[0]
-        if pipe.order == "morton":  # ordered batches: the next batch's indices exist already, batch k+2's are made
-            if pipe._idx_made[(k + 1) % 2] != k + 1:  # (an eager step that queued no late work: make them now,
-                pipe._produce_indices(k + 1)          #  on this stream, in front of the call's fork)
-            e2, b2 = divmod(k + 2, pipe.per_epoch)
-            seed2, first2 = ld.seed + 7919 * (pipe.epoch0 + e2), ld.span(b2)[0]
         if self.mode == "graph":
             i = self._slot = (self._slot + 1) % len(self._host_struct)
             if self._host_event[i] is not None:
@@ -948,8 +942,6 @@ class SteadyLoop:
         else:
             a = self._args[p]
             a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
-            if pipe.order == "morton":
-                a.seed2, a.first2 = seed2 & 0xFFFFFFFFFFFFFFFF, first2
             a.lr = opt.param_groups[0]["lr"]
             a.join_pending = 1 if self._join_pending else 0
             a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
@@ -980,8 +972,6 @@ class SteadyLoop:
         # what an eager step would have left behind
         opt.step_count += 1
         pipe._made[(k + 1) % 2] = k + 1
-        if pipe.order == "morton":
-            pipe._idx_made[k % 2] = k + 2
         pipe.advance()
         st._ws_index = self._wmap[p]
         st._ahead = dict(ptr=pipe.slots[1 - p][1].data_ptr(), n=ld.batch_size, ws=self._wmap[1 - p],

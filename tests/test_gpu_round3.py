@@ -520,6 +520,23 @@ def test_order_batch_is_a_deterministic_permutation(amd, shape, n):
         assert float(same) > 0.8, float(same)
 
 
+def test_order_gather_batch_equals_order_then_gather(amd):
+    """ops.order_gather_batch (the ordering's last launch gathers the rows) gives the indices, coordinates and targets
+    of ops.order_batch followed by the data set's gather, on a 3-D and the 4-D sample shape."""
+    dev = torch.device("cuda", 0)
+    for shape, n in (((48, 40, 36), 20000), ((22, 20, 6, 15), 33333)):
+        vol = torch.rand(shape, device=dev)
+        ds = amd.datamodules.MriImage(volume=vol, device=dev)
+        idx = torch.randperm(len(ds), device=dev)[:n].contiguous()
+        a = idx.clone()
+        amd.ops.order_batch(a, ds.shape)
+        c0, t0 = ds.batch(a)
+        b = idx.clone()
+        c1, t1 = amd.ops.order_gather_batch(b, ds.shape, ds.axes, ds.axis_offset, ds.pixels)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(c0, c1) and torch.equal(t0, t1)
+
+
 def test_ordered_batch_gives_the_same_step(amd):
     """A fused training step on a batch in Morton order and on the same rows in shuffle order: predictions and
     the gradient of the encoding are row-wise, the table gradient an exact sum -- bit-identical tables'
