@@ -12,7 +12,11 @@
 // launcher.py:156-165 -> models.py:61-70: training_step, backward, Adam.step; datamodules.py:198-205: the
 // DataLoader producing the next batch meanwhile), in the steady state of FusedStep.train_step with
 // count_ahead: same launches, same order, same data -- bit-identical parameters.
+#include <algorithm>
+#include <cstdint>
+
 #include "common.h"
+#include "hashgrid_common.h"  // FinTab: the table gradient's last conversion, done by the Adam kernel
 
 // Host-side cost of each call of a step, for tools/step_trace.py (a tools-only build with -DMRI_STEP_TRACE;
 // the shipped library compiles these to nothing): nanoseconds per slot, summed over calls.
@@ -109,16 +113,36 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
       return fail(MRI_ERR_LAUNCH, "fused step: join (count)");
   }
   const int32_t flags = a->bwd_method | MRI_BWD_PREPARED | MRI_BWD_OVERWRITE;
-  if ((rc = mri_hashgrid_backward_scaled(g, a->coords, a->d_enc, n, (int64_t)g->n_features * ld, 1, ld,
-                                         a->d_table, flags, 0xffffffffu, a->absmax, a->bwd_ws, a->bwd_ws_bytes,
-                                         main)))
-    return rc;
+  // The levels whose sums meet in the workspace's int64 area end with a conversion launch (bin_finalize_kernel, 8 us
+  // between the accumulation and Adam): when Adam follows at once over a range that holds the table's gradient, its
+  // kernel converts as it fetches (same expression, same bits) and the launch never happens.
+  FinTab fin{};
+  const bool fold = a->n_params > 0 && a->d_table >= a->grad && a->d_table < a->grad + a->n_params &&
+                    ((reinterpret_cast<uintptr_t>(a->param) | reinterpret_cast<uintptr_t>(a->grad) |
+                      reinterpret_cast<uintptr_t>(a->exp_avg) | reinterpret_cast<uintptr_t>(a->exp_avg_sq)) & 15) == 0;
+  if (fold) set_finalize_export(&fin);
+  rc = mri_hashgrid_backward_scaled(g, a->coords, a->d_enc, n, (int64_t)g->n_features * ld, 1, ld, a->d_table, flags,
+                                    0xffffffffu, a->absmax, a->bwd_ws, a->bwd_ws_bytes, main);
+  set_finalize_export(nullptr);  // (`fin` dies with this call)
+  if (rc) return rc;
   if (!phase(3)) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(phase)");
   TRACE(7)
-  if (a->n_params > 0 &&  // (0: a data-parallel caller reduces the gradient over the ranks first, then steps)
-      (rc = mri_adam_step(a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n_params, a->lr, a->beta1, a->beta2,
-                          a->eps, a->step, a->grad_scale, main)))
-    return rc;
+  if (fin.n > 0) {  // (taken: Adam owes the conversion)
+    const int64_t off = a->d_table - a->grad;
+    fin.lo = INT64_MAX, fin.hi = 0;
+    for (int s = 0; s < fin.n; ++s) {
+      fin.seg[s].begin += off;
+      fin.lo = std::min(fin.lo, fin.seg[s].begin);
+      fin.hi = std::max(fin.hi, fin.seg[s].begin + fin.seg[s].words);
+    }
+    MRI_REQUIRE(fin.hi <= a->n_params, "fused step: table gradient beyond the optimizer's range");
+    rc = adam_step_fin(a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n_params, a->lr, a->beta1, a->beta2, a->eps,
+                       a->step, a->grad_scale, fin, main);
+  } else if (a->n_params > 0) {  // (0: a data-parallel caller reduces the gradient over the ranks first, then steps)
+    rc = mri_adam_step(a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n_params, a->lr, a->beta1, a->beta2, a->eps,
+                       a->step, a->grad_scale, main);
+  }
+  if (rc) return rc;
   if (!phase(4)) return fail(MRI_ERR_LAUNCH, "fused step: hipEventRecord(phase)");
   TRACE(8)
   // the side work is joined by the NEXT call (join_pending = 1), or by the caller through `ev_join`

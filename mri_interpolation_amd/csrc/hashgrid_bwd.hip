@@ -108,13 +108,7 @@ struct Workspace {  // carved out of the caller's buffer
   int64_t records;
 };
 
-__device__ __forceinline__ int level_exponent(uint32_t max_bits, int64_t n) {
-  // e with n * max|g| * 2^e < 2^61: max|g| < 2^(E+1) (E = unbiased exponent), n < 2^log_n
-  const int E = (int)((max_bits >> 23) & 255u) - 127;
-  const int log_n = 64 - __clzll((unsigned long long)n);
-  const int e = 61 - (E + 1) - log_n;
-  return max(-90, min(e, 120));
-}
+// (level_exponent: hashgrid_common.h)
 
 __device__ __forceinline__ long long to_fixed(float v, float scale_hi) {
   // v * 2^e as int64 (e = log2(scale_hi) + 32): integer part of v * 2^(e-32) in the high
@@ -1057,6 +1051,8 @@ BinPlan select_levels(const BinPlan& plan, uint32_t mask, int& blocks) {
   return sel;
 }
 
+thread_local FinTab* tl_fin_out = nullptr;  // set_finalize_export(): taken by the next finalize that would launch
+
 template <int D, int F>
 struct BinnedLaunch {
   static int run(const LevelTab& tab, const BinPlan& plan, const BinPlan& dense_all,
@@ -1109,6 +1105,18 @@ struct BinnedLaunch {
           fin.ws_offset[fin.n_entries++] = sel.ws_offset[e];
         }
       auto finalize = [&]() {
+        if (fin.n_entries > 0 && tl_fin_out && overwrite && !ad.p) {
+          // the caller converts (set_finalize_export: the Adam kernel of mri_fused_step, as it fetches the gradient)
+          FinTab& t = *tl_fin_out;
+          tl_fin_out = nullptr;
+          t.n = fin.n_entries, t.max_bits = mx, t.n_coords = n;
+          for (int e = 0; e < fin.n_entries; ++e) {
+            const int level = fin.level_of[e];
+            t.seg[e].begin = (int64_t)tab.offset[level] * F, t.seg[e].words = (int64_t)tab.size[level] * F;
+            t.seg[e].src = w.partial + fin.ws_offset[e], t.seg[e].level = level;
+          }
+          return;
+        }
         if (fin.n_entries > 0)
           hipLaunchKernelGGL(bin_finalize_kernel, dim3(256, fin.n_entries), dim3(256), 0, st, tab,
                              fin, F, n, d_table, mx, w.partial, overwrite, ad);
@@ -1186,6 +1194,7 @@ struct BinnedLaunch {
 };
 
 }  // namespace
+void set_finalize_export(FinTab* out) { tl_fin_out = out; }
 }  // namespace mri
 
 using namespace mri;

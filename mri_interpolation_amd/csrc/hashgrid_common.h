@@ -23,6 +23,45 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t h, uint32_t size, uint32_t 
   return r >= size ? r - size : r;
 }
 
+// Exponent of the 64-bit fixed point a level's table gradient is summed in (hashgrid_bwd.hip): e with
+// n * max|g| * 2^e < 2^61: max|g| < 2^(E+1) (E = unbiased exponent of the level's max |d_out|), n < 2^log_n
+__device__ __forceinline__ int level_exponent(uint32_t max_bits, int64_t n) {
+  const int E = (int)((max_bits >> 23) & 255u) - 127;
+  const int log_n = 64 - __clzll((unsigned long long)n);
+  const int e = 61 - (E + 1) - log_n;
+  return max(-90, min(e, 120));
+}
+
+// Levels whose gradient sums meet in the int64 area of the table gradient's workspace (the dense levels, binned
+// levels cut over entry ranges) are converted to f32 by bin_finalize_kernel -- or, when the optimizer step follows
+// at once (mri_fused_step), by the Adam kernel itself as it fetches the gradient: the 8 us launch between the
+// accumulation and Adam goes.  One segment per such level, in elements of the buffer the consumer walks.
+struct FinSeg {
+  int64_t begin, words;
+  const unsigned long long* src;
+  int level, pad;
+};
+struct FinTab {
+  int n = 0, pad = 0;
+  int64_t lo = 0, hi = 0;            // [lo, hi) covers every segment
+  const uint32_t* max_bits = nullptr;  // per level: bit pattern of max |d_out|
+  int64_t n_coords = 0;
+  FinSeg seg[MRI_MAX_LEVELS];
+};
+// the f32 gradient of element e (inside segment s), as bin_finalize_kernel computes it
+__device__ __forceinline__ float fin_value(const FinTab& f, int s, int64_t e) {
+  const double inv_scale = __builtin_ldexp(1.0, -level_exponent(f.max_bits[f.seg[s].level], f.n_coords));
+  return (float)((double)(long long)f.seg[s].src[e - f.seg[s].begin] * inv_scale);
+}
+// hashgrid_bwd.hip: the next table-gradient call on this thread that would launch bin_finalize_kernel (overwrite
+// mode) fills *out instead (segments in elements of d_table) and leaves the conversion to the caller
+void set_finalize_export(FinTab* out);
+// train_ops.hip: mri_adam_step over a 16-byte aligned range whose gradient comes from `fin` where a segment covers
+// it (segments in elements of the range), from `grad` elsewhere
+int adam_step_fin(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                  double beta1, double beta2, double eps, int32_t step, float grad_scale, const FinTab& fin,
+                  hipStream_t stream);
+
 // corner loops are fully unrolled up to 4-D (16 corners), by 2 beyond
 template <int D>
 constexpr int kCornerUnroll = D <= 4 ? (1 << D) : 2;

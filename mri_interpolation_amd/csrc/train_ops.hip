@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "hashgrid_common.h"  // FinTab: the table gradient's int64 sums, converted by the Adam kernel
 
 namespace mri {
 
@@ -55,13 +56,16 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__
 //   p = p + (-step_size * m) / (sqrt(v) / sqrt(bc2) + eps)    (addcdiv_)
 // `dev` (hipGraph replays: the step-dependent prefactors cannot be baked into a captured launch): when
 // non-null, the scalars are read from that device-resident block instead of the by-value arguments.
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
-                                                   const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t count, float one_minus_b1, float b2,
-                                                   float one_minus_b2, float neg_step_size,
-                                                   float bc2_sqrt, float eps, float grad_scale,
-                                                   int head, const mri_step_params* __restrict__ dev) {
+// FIN (mri_fused_step): where a segment of `fin` covers an element, its gradient is the table gradient's int64 sum,
+// converted here exactly as bin_finalize_kernel would have (hashgrid_common.h) -- that launch then never happens.
+template <bool FIN>
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g,
+                                          float* __restrict__ m, float* __restrict__ v,
+                                          int64_t count, float one_minus_b1, float b2,
+                                          float one_minus_b2, float neg_step_size,
+                                          float bc2_sqrt, float eps, float grad_scale,
+                                          int head, const mri_step_params* __restrict__ dev,
+                                          const FinTab& fin) {
   if (dev) {  // wave-uniform scalar loads
     one_minus_b1 = dev->one_minus_b1, b2 = dev->b2, one_minus_b2 = dev->one_minus_b2;
     neg_step_size = dev->neg_step_size, bc2_sqrt = dev->bc2_sqrt, eps = dev->eps;
@@ -85,7 +89,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
     // gradient and moments are touched once per step: non-temporal accesses keep them from
     // evicting the parameters (the next forward pass gathers from them) -- 10 us per step
     typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v g_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g + base));
+    f4v g_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g + base));
+    if (FIN && base + 3 >= fin.lo && base < fin.hi) {
+      for (int s = 0; s < fin.n; ++s) {
+        const int64_t b0 = fin.seg[s].begin, b1 = b0 + fin.seg[s].words;
+        if (base + 3 < b0 || base >= b1) continue;
+        if (base >= b0 && base < b1) g_.x = fin_value(fin, s, base);
+        if (base + 1 >= b0 && base + 1 < b1) g_.y = fin_value(fin, s, base + 1);
+        if (base + 2 >= b0 && base + 2 < b1) g_.z = fin_value(fin, s, base + 2);
+        if (base + 3 >= b0 && base + 3 < b1) g_.w = fin_value(fin, s, base + 3);
+      }
+    }
     const f4v m_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + base));
     const f4v v_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + base));
     const float4 gv4 = make_float4(g_.x, g_.y, g_.z, g_.w);
@@ -111,13 +125,36 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
     __builtin_nontemporal_store(vo, reinterpret_cast<f4v*>(v + base));
   } else {
     for (int64_t e = base; e < count; ++e) {
-      const float gr = g[e] * grad_scale;
+      float ge = g[e];
+      if (FIN && e >= fin.lo && e < fin.hi)
+        for (int s = 0; s < fin.n; ++s)
+          if (e >= fin.seg[s].begin && e < fin.seg[s].begin + fin.seg[s].words) ge = fin_value(fin, s, e);
+      const float gr = ge * grad_scale;
       m[e] = m[e] + (gr - m[e]) * one_minus_b1;
       v[e] = v[e] * b2 + (one_minus_b2 * gr) * gr;
       const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
       p[e] = p[e] + (neg_step_size * m[e]) / denom;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t count, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float neg_step_size,
+                                                   float bc2_sqrt, float eps, float grad_scale,
+                                                   int head, const mri_step_params* __restrict__ dev) {
+  adam_body<false>(p, g, m, v, count, one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, head,
+                   dev, FinTab{});
+}
+__global__ __launch_bounds__(256) void adam_fin_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       int64_t count, float one_minus_b1, float b2,
+                                                       float one_minus_b2, float neg_step_size,
+                                                       float bc2_sqrt, float eps, float grad_scale,
+                                                       const FinTab fin) {
+  adam_body<true>(p, g, m, v, count, one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, 0,
+                  nullptr, fin);
 }
 
 // ---------------------------------------------------------------------------------- sampler
@@ -185,6 +222,22 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const int64_t* __rest
 }
 
 }  // namespace
+
+int adam_step_fin(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                  double beta1, double beta2, double eps, int32_t step, float grad_scale, const FinTab& fin,
+                  hipStream_t stream) {
+  MRI_REQUIRE(count >= 1 && step >= 1 && param && grad && exp_avg && exp_avg_sq, "adam_step_fin: bad arguments");
+  MRI_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
+              "adam_step_fin: 16-byte aligned buffers");
+  const double bc1 = 1.0 - pow(beta1, (double)step);  // scalar prefactors in double, as torch computes them on the host
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const int64_t blocks = std::max<int64_t>(1, ceil_div(ceil_div(count, 4), 256));
+  hipLaunchKernelGGL(adam_fin_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq,
+                     count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(-(lr / bc1)),
+                     (float)sqrt(bc2), (float)eps, grad_scale, fin);
+  return check_launch("adam_fin_kernel");
+}
 }  // namespace mri
 
 using namespace mri;
