@@ -49,8 +49,10 @@ struct FinTab {
   FinSeg seg[MRI_MAX_LEVELS];
 };
 // the f32 gradient of element e (inside segment s), as bin_finalize_kernel computes it
-__device__ __forceinline__ float fin_value(const FinTab& f, int s, int64_t e) {
-  const double inv_scale = __builtin_ldexp(1.0, -level_exponent(f.max_bits[f.seg[s].level], f.n_coords));
+__device__ __forceinline__ double fin_inv_scale(const FinTab& f, int s) {
+  return __builtin_ldexp(1.0, -level_exponent(f.max_bits[f.seg[s].level], f.n_coords));
+}
+__device__ __forceinline__ float fin_value(const FinTab& f, int s, int64_t e, double inv_scale) {
   return (float)((double)(long long)f.seg[s].src[e - f.seg[s].begin] * inv_scale);
 }
 // hashgrid_bwd.hip: the next table-gradient call on this thread that would launch bin_finalize_kernel (overwrite

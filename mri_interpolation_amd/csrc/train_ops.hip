@@ -94,10 +94,11 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
       for (int s = 0; s < fin.n; ++s) {
         const int64_t b0 = fin.seg[s].begin, b1 = b0 + fin.seg[s].words;
         if (base + 3 < b0 || base >= b1) continue;
-        if (base >= b0 && base < b1) g_.x = fin_value(fin, s, base);
-        if (base + 1 >= b0 && base + 1 < b1) g_.y = fin_value(fin, s, base + 1);
-        if (base + 2 >= b0 && base + 2 < b1) g_.z = fin_value(fin, s, base + 2);
-        if (base + 3 >= b0 && base + 3 < b1) g_.w = fin_value(fin, s, base + 3);
+        const double inv = fin_inv_scale(fin, s);
+        if (base >= b0 && base < b1) g_.x = fin_value(fin, s, base, inv);
+        if (base + 1 >= b0 && base + 1 < b1) g_.y = fin_value(fin, s, base + 1, inv);
+        if (base + 2 >= b0 && base + 2 < b1) g_.z = fin_value(fin, s, base + 2, inv);
+        if (base + 3 >= b0 && base + 3 < b1) g_.w = fin_value(fin, s, base + 3, inv);
       }
     }
     const f4v m_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + base));
@@ -128,7 +129,8 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
       float ge = g[e];
       if (FIN && e >= fin.lo && e < fin.hi)
         for (int s = 0; s < fin.n; ++s)
-          if (e >= fin.seg[s].begin && e < fin.seg[s].begin + fin.seg[s].words) ge = fin_value(fin, s, e);
+          if (e >= fin.seg[s].begin && e < fin.seg[s].begin + fin.seg[s].words)
+            ge = fin_value(fin, s, e, fin_inv_scale(fin, s));
       const float gr = ge * grad_scale;
       m[e] = m[e] + (gr - m[e]) * one_minus_b1;
       v[e] = v[e] * b2 + (one_minus_b2 * gr) * gr;
