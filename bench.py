@@ -22,8 +22,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the variable is read
-# when HIP initialises, so it is set before torch is imported (an explicit setting wins)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# when HIP initialises, so it is set before torch is imported -- for a multi-process launch only, and an
+# explicit setting wins (mri_interpolation_amd/parallel.py: ipc_default)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # exact-f32 matrix rate (no xf32 on gfx950)
@@ -300,11 +302,12 @@ def main():
                     help="time the first leg on a device that has just left idle (the order until round 3: timed legs, "
                          "then the quality leg); by default the quality leg's training steps run first, so that every "
                          "timed leg sees settled clocks")
-    ap.add_argument("--phase-every", type=int, default=32,
+    ap.add_argument("--phase-every", type=int, default=0,
                     help="bracket the phases with HIP events on every n-th timed step only (the 4th, the (n+4)th, "
-                         "...: one sample in a 20-step run, six in the default 200): a timing event is a "
-                         "serialisation point, five per step cost 0.15 ms (0.71 against 0.56 ms per step with "
-                         "n = 1, round 3)")
+                         "...): a timing event is a serialisation point, five per step cost 0.15 ms (0.71 against "
+                         "0.56 ms per step with n = 1, round 3).  0 (default) = max(4, steps // 5): five sampled "
+                         "steps whatever the run length (the driver's 20-step form: every 4th), so that "
+                         "phases_ms / rooflines.*.ms_per_launch are means of >= 3 launches")
     ap.add_argument("--launch", default="native", choices=["native", "graph", "eager"],
                     help="how a step is queued (trainer.SteadyLoop): native = one mri_fused_step call per step; "
                          "graph = hipGraph replay; eager = op by op from Python")
@@ -345,6 +348,8 @@ def main():
     ap.add_argument("--grad-buckets", type=int, default=0,
                     help="level groups of the table-gradient kernels (0 = default)")
     args = ap.parse_args()
+    if args.phase_every <= 0:
+        args.phase_every = max(4, args.steps // 5)
 
     import torch
     from mri_interpolation_amd import _lib, datamodules, parallel, trainer
@@ -475,10 +480,12 @@ def main():
         elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
         step.phase_events = events
         phases = step.phase_ms()
+        n_samples = min((len(v) for v in events.values()), default=0)
         step.phase_events, sampling[0] = None, False
         if hasattr(step, "check_status"):
             step.check_status()  # the overlapped decoder's wait for the lookup must never have timed out
         return dict(elapsed=elapsed, phases=phases, host_ms=host_ms, loss=float(loss),
+                    phase_samples=n_samples,
                     ms_per_step=elapsed / steps * 1e3, value=w["batch"] * world * steps / elapsed)
 
     def replicas_identical():
@@ -505,18 +512,34 @@ def main():
         plan = [(args.dp_mode + (f"_{step.grad_buckets}" if args.dp_mode == "all_reduce" else ""),
                  args.dp_mode, step.grad_buckets)]
     legs, partial_line = {}, [None]
-    watchdog = None
-    if world > 1 and len(plan) > 1:
-        import threading
+    watchdog, current_leg = [None], [None]
 
-        def give_up():  # a later leg hangs in its first contact with RCCL: keep the line we have
-            if rank == 0 and partial_line[0] is not None:
-                partial_line[0]["aborted"] = "a later gradient-exchange leg did not finish within " \
-                                             f"{args.leg_timeout} s; this line holds the legs that did"
-                print(json.dumps(partial_line[0]), flush=True)
-            os._exit(0 if partial_line[0] is not None or rank != 0 else 3)
-        watchdog = threading.Timer(args.leg_timeout, give_up)
-        watchdog.daemon = True
+    def give_up():
+        """A gradient-exchange leg after the first did not finish (it hangs in its first contact with a real
+        multi-GPU RCCL): the line of the finished legs is still printed, with an entry naming the leg that hung,
+        and EVERY rank exits non-zero -- a collective that hangs is a failed run, to be investigated from that
+        record, not a success with a footnote."""
+        name, mode, buckets = current_leg[0]
+        if rank == 0 and partial_line[0] is not None:
+            line = partial_line[0]
+            line["aborted"] = (f"leg {name!r} (dp_mode {mode}, grad_buckets {buckets}) did not finish within "
+                               f"{args.leg_timeout} s; this line holds the legs that did")
+            line.setdefault("collectives", {}).setdefault("legs", {})[name] = dict(
+                error=f"timeout after {args.leg_timeout} s", dp_mode=mode, grad_buckets=buckets, identical=False)
+            print(json.dumps(line), flush=True)
+        os._exit(4)
+
+    def arm_watchdog(leg):  # one budget per leg, so that the record says WHICH leg hung
+        import threading
+        current_leg[0] = leg
+        watchdog[0] = threading.Timer(args.leg_timeout, give_up)
+        watchdog[0].daemon = True
+        watchdog[0].start()
+
+    def disarm_watchdog():
+        if watchdog[0] is not None:
+            watchdog[0].cancel()
+            watchdog[0] = None
 
     def finish(best_name, psnr=None, packed=None, cpu=None):
         """The result line from the legs measured so far (rank 0)."""
@@ -558,6 +581,7 @@ def main():
             "rooflines": rooflines,
             "phases_ms": {k: round(v, 4) for k, v in sorted(phases.items())},
             "phases_sampled_every": max(1, args.phase_every),
+            "phases_samples": best.get("phase_samples"),  # launches behind each phases_ms / ms_per_launch mean
             "host_queue_ms_per_step": round(best["host_ms"], 4),
             "launch": {"native": "one mri_fused_step call per step (phase events recorded inside the call)",
                        "graph": "hipGraph replay per step (sample steps eager)"}[args.launch]
@@ -662,17 +686,20 @@ def main():
             if graphed[0] is not None:
                 graphed[0].finish()
             capture_graphs()  # (the plain all-reduce leg is queued natively, the other forms op by op)
-        if i == 1 and watchdog is not None:
-            watchdog.start()
+        if i >= 1 and world > 1:
+            arm_watchdog((name, mode, buckets))
         try:
             leg = timed_leg(args.warmup, args.steps)
         except Exception as exc:  # a variant may be refused (e.g. shards that do not divide): say so
+            disarm_watchdog()
             if i == 0:
                 raise
             legs[name] = dict(error=repr(exc), identical=False, value=0.0, ms_per_step=0.0, phases={}, groups=[],
                               dp_mode=mode, grad_buckets=buckets, host_ms=0.0, loss=float("nan"))
             continue
-        leg.update(dp_mode=mode, grad_buckets=buckets, identical=replicas_identical(),
+        identical = replicas_identical()  # (a collective too: still under the leg's watchdog)
+        disarm_watchdog()
+        leg.update(dp_mode=mode, grad_buckets=buckets, identical=identical,
                    launch="native" if graphed[0] is not None else "eager",
                    groups=[dict(bytes=b, wait_ms=round(leg["phases"].get(f"reduce_wait_{j}", 0.0), 4))
                            for j, b in enumerate(getattr(step, "last_group_bytes", []))]
@@ -680,8 +707,6 @@ def main():
         legs[name] = leg
         if rank == 0 and world > 1:
             partial_line[0] = finish(best_leg()) if any(v["identical"] for v in legs.values()) else None
-    if watchdog is not None:
-        watchdog.cancel()
     best = best_leg()
     if world > 1:  # continue (PSNR steps) in the mode the line reports
         step.dp_mode, step.grad_buckets, step._bucket_cache = legs[best]["dp_mode"], legs[best]["grad_buckets"], None

@@ -19,8 +19,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# read when HIP initialises (RCCL's dmabuf IPC between the ranks of a node): set before torch loads
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# RCCL's dmabuf IPC between the ranks of a node is read when HIP initialises: set before torch loads,
+# and only for a multi-process launch (mri_interpolation_amd/parallel.py: ipc_default)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def parse_args(argv=None):
@@ -53,6 +55,14 @@ def parse_args(argv=None):
     p.add_argument("--checkpoint_path", type=str,
                    help="resume the parameters from a checkpoint (what the reference does through "
                         "model_cls.load_from_checkpoint when config.checkpoint_path is set)")
+    p.add_argument("--resume_optimizer", action="store_true",
+                   help="with --checkpoint_path: also restore Adam's moments and step count (Lightning's "
+                        "fit(ckpt_path=)); the default is the reference's resume, a fresh Adam at --lr")
+    p.add_argument("--restore_lr", action="store_true",
+                   help="with --resume_optimizer: take the checkpoint's learning rate instead of --lr")
+    p.add_argument("--unsafe_checkpoint", action="store_true",
+                   help="read --checkpoint_path with the unrestricted unpickler (Lightning files holding "
+                        "callback objects); executes code from the file")
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--max_steps", type=int, default=-1)
     p.add_argument("--log_every", type=int, default=50)
@@ -101,6 +111,7 @@ def main(argv=None):
         config.enco_config = cfg.load_json(enco_path)  # reference launcher.py:73-74
     overrides = {k: v for k, v in vars(args).items()
                  if k not in ("synthetic", "tiny_mlp", "out_dir", "max_steps", "log_every",
+                              "resume_optimizer", "restore_lr", "unsafe_checkpoint",
                               "enco_config_path", "holdout_odd_frames", "base_resolution",
                               "finest_resolution")}
     cfg.apply_overrides(config, overrides)
@@ -136,10 +147,13 @@ def main(argv=None):
     model = build_model(config, models).cuda()
     if config.checkpoint_path:  # reference launcher.py:97-117 (model_cls.load_from_checkpoint)
         from mri_interpolation_amd import checkpoint
-        # parameters AND the optimiser's moments / step count: resuming must not restart Adam's bias
-        # correction (Trainer.fit reuses model.optimizer)
+        # The reference restores the WEIGHTS and then fits with a fresh Adam at config.lr (no ckpt_path in
+        # trainer.fit, launcher.py:165): that is the default here too.  --resume_optimizer restores the
+        # moments and the step count as Lightning's fit(ckpt_path=) would (Trainer.fit reuses model.optimizer).
         model.optimizer = model.configure_optimizers()
-        checkpoint.load(config.checkpoint_path, model, model.optimizer, map_location="cuda")
+        checkpoint.load(config.checkpoint_path, model, model.optimizer, map_location="cuda",
+                        resume_optimizer=args.resume_optimizer, restore_lr=args.restore_lr,
+                        allow_pickle=args.unsafe_checkpoint)
     datamodule = datamodules.MriDataModule(config=config, volume=volume,
                                            norm_siren=config.norm_siren)
     datamodule.prepare_data()
@@ -160,6 +174,8 @@ def main(argv=None):
     trainer.fit(model, train_loader)
     train_seconds = time.time() - t0
     if world > 1:  # every rank leaves the group together; rank 0 alone writes the artefacts
+        if getattr(model, "optimizer", None) is not None:
+            parallel.gather_optimizer_state(model.optimizer, rank, world)  # reduce_scatter: moments made whole
         parallel.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -180,7 +196,7 @@ def main(argv=None):
     # layout Lightning writes (checkpoint.py): the reference's load_from_checkpoint reads it
     from mri_interpolation_amd import checkpoint
     os.makedirs(os.path.join(out_dir, "checkpoints"), exist_ok=True)
-    if rank == 0:
+    if rank == 0:  # (a sharded optimiser state was gathered before the ranks parted, below)
         checkpoint.save(os.path.join(out_dir, "checkpoints",
                                      f"epoch={config.epochs - 1}-step={trainer.global_step}.ckpt"),
                         model, getattr(model, "optimizer", None), epoch=config.epochs - 1,

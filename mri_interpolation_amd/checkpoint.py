@@ -10,8 +10,12 @@ reference's `HashMLP`), and -- for `Trainer.fit(ckpt_path=...)` --
 the REFERENCE module), `"lr_schedulers"`, `"epoch"`, `"global_step"`.
 
 This module writes exactly that from the MI355X-side classes (whose hash tables are ONE flat parameter and
-whose Adam moments live in one flat buffer) and reads it back, moments and step count included, so that
-`launcher.py --checkpoint_path` resumes the optimiser instead of restarting its bias correction.
+whose Adam moments live in one flat buffer) and reads it back.  `load()` restores the PARAMETERS only by
+default -- what the reference's resume does: `load_from_checkpoint(path, ..., lr=config.lr)` followed by
+`trainer.fit(model, loader)` WITHOUT `ckpt_path` (reference launcher.py:97-165), i.e. a fresh Adam at the
+command line's learning rate.  `resume_optimizer=True` (launcher `--resume_optimizer`) is the equivalent
+of Lightning's `fit(ckpt_path=...)`: moments and step count come back too; the learning rate of the file
+replaces the configured one only with `restore_lr=True`.
 Host logic only: no kernel is involved.
 """
 from collections import OrderedDict
@@ -30,10 +34,13 @@ def _dead_base_stack(model) -> "OrderedDict[str, torch.Tensor]":
     (what Lightning would have saved: never trained)."""
     out = OrderedDict()
     n_layers = int(getattr(model, "n_layers", 0))
-    for i in range(n_layers):
-        lin = nn.Linear(2 if i == 0 else 128, 1 if i == n_layers - 1 else 128)
-        out[f"layers.{2 * i}.weight"] = lin.weight.detach().clone()
-        out[f"layers.{2 * i}.bias"] = lin.bias.detach().clone()
+    # a forked, seeded generator: saving neither advances the caller's RNG nor depends on it
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(1337)
+        for i in range(n_layers):
+            lin = nn.Linear(2 if i == 0 else 128, 1 if i == n_layers - 1 else 128)
+            out[f"layers.{2 * i}.weight"] = lin.weight.detach().clone()
+            out[f"layers.{2 * i}.bias"] = lin.bias.detach().clone()
     return out
 
 
@@ -56,6 +63,12 @@ def _reference_parameter_names(model):
 
 def _moments_by_name(model, optimizer) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
     """{state-dict key: (exp_avg, exp_avg_sq)} from the flat Adam buffers, the table's per level."""
+    if getattr(optimizer, "sharded", False):
+        # dp_mode "reduce_scatter": a rank steps -- and holds the moments of -- its 1/world shard only
+        # (optim.Adam.step_shard); the other shards of the local buffers are stale
+        raise RuntimeError("checkpoint.save: the optimiser state is sharded over the ranks (dp_mode "
+                           "'reduce_scatter'); gather it first (parallel.gather_optimizer_state) "
+                           "or save with dp_mode 'all_reduce'")
     flat = optimizer.flatten()
     out = {}
     own = {id(p): n for n, p in model.named_parameters()}
@@ -120,17 +133,24 @@ def save(path: str, model, optimizer=None, epoch: int = 0, global_step: int = 0)
     return ckpt
 
 
-def load(path: str, model, optimizer=None, map_location="cpu") -> dict:
-    """Load parameters (and, given this package's optim.Adam, the moments and the step count) from a
-    checkpoint written by save() or by Lightning for the reference module; returns the checkpoint.
-    `layers.*` of a reference HashMLP checkpoint is dropped by the model's own loader (models.py)."""
-    try:  # what save() writes needs nothing beyond tensors and containers
-        ckpt = torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:  # a Lightning checkpoint may hold callback / hyper-parameter objects
-        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+def load(path: str, model, optimizer=None, map_location="cpu", resume_optimizer: bool = False,
+         restore_lr: bool = False, allow_pickle: bool = False) -> dict:
+    """Load the parameters from a checkpoint written by save() or by Lightning for the reference module;
+    returns the checkpoint.  `layers.*` of a reference HashMLP checkpoint is dropped by the model's own
+    loader (models.py).
+    resume_optimizer: also restore Adam's moments and step count into `optimizer` (this package's
+        optim.Adam) -- Lightning's `fit(ckpt_path=)`; the default leaves the optimiser as constructed,
+        which is what the reference's launcher does (launcher.py:97-165).
+    restore_lr: with resume_optimizer, take the learning rate of the file instead of the configured one.
+    allow_pickle: what save() writes needs nothing beyond tensors and containers and is read with
+        `weights_only=True`; a Lightning checkpoint holding callback / hyper-parameter objects needs the
+        unrestricted unpickler, which executes code from the file: opt in explicitly for files you trust."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=not allow_pickle)
     model.load_state_dict(ckpt.get("state_dict", ckpt))
     states = ckpt.get("optimizer_states") or []
-    if optimizer is not None and states and states[0].get("state"):
+    if resume_optimizer and optimizer is None:
+        raise ValueError("resume_optimizer=True needs the optimiser to restore into")
+    if resume_optimizer and states and states[0].get("state"):
         names = _reference_parameter_names(model)
         by_name = {names[int(i)]: s for i, s in states[0]["state"].items()}
         flat = optimizer.flatten()
@@ -160,6 +180,7 @@ def load(path: str, model, optimizer=None, map_location="cpu") -> dict:
                              "the flat optimiser keeps one")
         if steps:
             optimizer.step_count = steps.pop()
-        group = states[0]["param_groups"][0]
-        optimizer.param_groups[0]["lr"] = group.get("lr", optimizer.param_groups[0]["lr"])
+        if restore_lr:
+            group = states[0]["param_groups"][0]
+            optimizer.param_groups[0]["lr"] = group.get("lr", optimizer.param_groups[0]["lr"])
     return ckpt

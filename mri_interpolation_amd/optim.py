@@ -68,6 +68,9 @@ class Adam:
         self.step_count = 0
         self.flat: Optional[FlatBuffers] = None
         self.grad_scale = 1.0  # 1/world_size after an all-reduce(sum)
+        # True once step_shard() has run with world > 1: the local moment buffers then hold this rank's
+        # shard only (checkpoint.save refuses until parallel.gather_optimizer_state has made them whole)
+        self.sharded = False
         self.param_groups = [dict(params=self._params, lr=lr, betas=betas, eps=eps)]
 
     def flatten(self) -> FlatBuffers:

@@ -26,10 +26,7 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the process group described by the environment; no-op for a single process."""
     rank, world, local = env_world()
-    # RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC
-    # mode is not supported by every host driver (hipIpcGetMemHandle: invalid argument).  Only a
-    # default: an explicit setting of the launcher wins, and it is read when HIP initialises.
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ipc_default(world)
     if world > 1 and not dist.is_initialized():
         if backend is None:  # "nccl" is RCCL on ROCm; MRI_DIST_BACKEND=gloo rehearses on one GPU
             backend = os.environ.get("MRI_DIST_BACKEND",
@@ -39,6 +36,17 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def ipc_default(world: Optional[int] = None) -> None:
+    """RCCL shares device buffers between the ranks of a node through dmabuf IPC; the legacy IPC mode is
+    not supported by every host driver (hipIpcGetMemHandle: invalid argument).  Multi-process runs only,
+    and only a default: an explicit setting of the launcher wins.  Read when HIP initialises, so entry
+    points call this before anything touches the GPU; a single process never sets it."""
+    if world is None:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def world_size() -> int:
@@ -103,32 +111,62 @@ def shard_range(numel: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+_staging = {}  # (device, dtype, numel) -> shard-sized buffer: the collectives below never alias
+
+
+def _shard_staging(like: torch.Tensor) -> torch.Tensor:
+    key = (like.device, like.dtype, like.numel())
+    buf = _staging.get(key)
+    if buf is None:
+        _staging.clear()  # one shard size per process at a time
+        buf = _staging[key] = torch.empty_like(like)
+    return buf
+
+
 def reduce_scatter_sum(flat: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """Sum `flat` over ranks, leaving this rank's shard (shard_range) reduced IN PLACE in `flat`
-    and returning that view; the other shards of `flat` hold garbage afterwards.  RCCL:
-    reduce_scatter (each rank receives 1/world of the bytes an all-reduce moves to it); gloo
-    has no reduce_scatter, so the CPU rehearsal all-reduces and keeps the shard."""
+    """Sum `flat` over ranks, leaving this rank's shard (shard_range) reduced in `flat` and returning that
+    view; the other shards of `flat` hold garbage afterwards.  RCCL: reduce_scatter (each rank receives
+    1/world of the bytes an all-reduce moves to it) into a STAGING buffer of one shard (6 MB at config 4,
+    8 ranks) that is copied back: input and output of the collective never overlap -- the in-place form
+    `reduce_scatter_tensor(flat[lo:hi], flat)` is legal NCCL but has never met a multi-GPU RCCL here.
+    gloo has no reduce_scatter, so the CPU rehearsal all-reduces and keeps the shard."""
     lo, hi = shard_range(flat.numel(), rank, world)
     shard = flat[lo:hi]
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+            out = _shard_staging(shard)
+            dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM)
+            shard.copy_(out)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return shard
 
 
 def all_gather_shards(flat: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """Every rank contributes its shard of `flat` (in place) and receives all the others."""
+    """Every rank contributes its shard of `flat` and receives all the others (the shard is sent from a
+    staging copy: the collective's input never lies inside its output)."""
     lo, hi = shard_range(flat.numel(), rank, world)
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(flat, flat[lo:hi])
+            src = _shard_staging(flat[lo:hi])
+            src.copy_(flat[lo:hi])
+            dist.all_gather_into_tensor(flat, src)
         else:
             parts = [torch.empty_like(flat[lo:hi]) for _ in range(world)]
             dist.all_gather(parts, flat[lo:hi].clone())
             flat.copy_(torch.cat(parts))
     return flat
+
+
+def gather_optimizer_state(optimizer, rank: int, world: int) -> None:
+    """dp_mode "reduce_scatter" leaves every rank with the Adam moments of its own shard only; before a
+    checkpoint is written every rank calls this: the padded moment buffers are all-gathered shard by shard
+    (as the parameters are after every step) and the optimiser is marked whole again."""
+    flat = optimizer.flatten()
+    if getattr(optimizer, "sharded", False) and world > 1:
+        all_gather_shards(flat._exp_avg_all, rank, world)
+        all_gather_shards(flat._exp_avg_sq_all, rank, world)
+    optimizer.sharded = False
 
 
 def wait_all(handles):

@@ -673,6 +673,7 @@ class FusedStep:
                 lo, hi = parallel.shard_range(all_grads.numel(), self.rank, self.world)
                 self.opt.begin_step()
                 self.opt.step_shard(lo, hi)
+                self.opt.sharded = True  # the moments of the other shards are stale from here on
                 with self._phase("reduce_wait_1"):
                     parallel.all_gather_shards(self.flat._param_all, self.rank, self.world)
         elif self.world > 1 and self._pending:

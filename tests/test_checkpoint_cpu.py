@@ -79,7 +79,7 @@ def test_layout_and_round_trip(tmp_path, build):
         for p in fresh.parameters():
             p.add_(1.0)
     adam = _CpuAdam(fresh)
-    checkpoint.load(path, fresh, adam)
+    checkpoint.load(path, fresh, adam, resume_optimizer=True)
     for (k, a), (_, b) in zip(model.state_dict().items(), fresh.state_dict().items()):
         assert torch.equal(a, b), k
     assert adam.step_count == 40 and adam.param_groups[0]["lr"] == model.lr
@@ -156,3 +156,81 @@ def _check_reference_load(tmp_path, kind, ref_models):
             continue
         assert st["exp_avg"].shape == p.shape and float(st["step"]) == 9.0
         assert torch.equal(st["exp_avg"], moments[names[i]][0])
+
+
+def test_default_resume_is_the_references_weights_only_with_a_fresh_adam(tmp_path):
+    """Reference launcher.py:97-165: `load_from_checkpoint(path, ..., lr=config.lr)` then `trainer.fit(model,
+    loader)` with no ckpt_path -- the weights come back, Adam starts at step 0 with zero moments at the
+    COMMAND LINE's learning rate.  `resume_optimizer=True` is Lightning's fit(ckpt_path=): moments and step
+    count too, still at the configured lr unless `restore_lr=True`."""
+    model = _hash()
+    moments = _fake_moments(model, 5)
+    path = str(tmp_path / "c.ckpt")
+    torch.save(checkpoint.lightning_checkpoint(model, epoch=0, global_step=7, moments=moments, step=7), path)
+    assert torch.load(path, weights_only=True)["optimizer_states"][0]["param_groups"][0]["lr"] == model.lr
+
+    def fresh_pair(lr):
+        fresh = _hash()
+        with torch.no_grad():
+            for p in fresh.parameters():
+                p.add_(1.0)
+        adam = _CpuAdam(fresh)
+        adam.param_groups[0]["lr"] = lr  # what `--lr` configured
+        return fresh, adam
+
+    fresh, adam = fresh_pair(1e-2)
+    checkpoint.load(path, fresh, adam)  # the default
+    for (k, a), (_, b) in zip(model.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert adam.step_count == 0 and adam.param_groups[0]["lr"] == 1e-2
+    assert not adam.flat.exp_avg.any() and not adam.flat.exp_avg_sq.any()
+
+    fresh, adam = fresh_pair(1e-2)
+    checkpoint.load(path, fresh, adam, resume_optimizer=True)
+    assert adam.step_count == 7 and adam.param_groups[0]["lr"] == 1e-2 and adam.flat.exp_avg.any()
+
+    fresh, adam = fresh_pair(1e-2)
+    checkpoint.load(path, fresh, adam, resume_optimizer=True, restore_lr=True)
+    assert adam.step_count == 7 and adam.param_groups[0]["lr"] == model.lr
+    with pytest.raises(ValueError):
+        checkpoint.load(path, fresh, None, resume_optimizer=True)
+
+
+def test_load_never_unpickles_objects_unless_asked(tmp_path):
+    """A file that needs the unrestricted unpickler is refused (the original error surfaces, nothing is
+    retried behind the caller's back); `allow_pickle=True` is the explicit opt-in."""
+    model = _siren()
+    ckpt = checkpoint.lightning_checkpoint(model, epoch=0, global_step=1, moments=_fake_moments(model, 3), step=1)
+    ckpt["callbacks"] = {"cb": _Opaque()}
+    path = str(tmp_path / "lightning.ckpt")
+    torch.save(ckpt, path)
+    import pickle
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.load(path, _siren())
+    checkpoint.load(path, _siren(), allow_pickle=True)
+    with pytest.raises(FileNotFoundError):  # genuine errors are not masked either
+        checkpoint.load(str(tmp_path / "missing.ckpt"), _siren())
+
+
+class _Opaque:
+    """Stands for the callback / hyper-parameter objects a Lightning checkpoint may hold."""
+
+
+def test_saving_is_deterministic_and_leaves_the_rng_alone():
+    model = _hash()
+    torch.manual_seed(99)
+    before = torch.random.get_rng_state()
+    a = checkpoint.reference_state_dict(model)
+    assert torch.equal(before, torch.random.get_rng_state())
+    torch.manual_seed(5)
+    b = checkpoint.reference_state_dict(model)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_a_sharded_optimizer_state_is_refused():
+    model = _siren()
+    adam = _CpuAdam(model)
+    adam.sharded = True
+    with pytest.raises(RuntimeError, match="sharded"):
+        checkpoint._moments_by_name(model, adam)

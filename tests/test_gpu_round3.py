@@ -284,8 +284,10 @@ def test_hashmlp_batchnorm_decoder_gradients_and_adam(amd):
 # --------------------------------------------------------------------------- checkpoints
 def test_launcher_checkpoint_resumes_parameters_and_optimizer(amd, tmp_path):
     """`launcher.py` writes Lightning's default checkpoint in Lightning's layout (checkpoint.py); loaded
-    into a fresh model + optimiser it restores parameters, BOTH Adam moments and the step count bit for
-    bit, and `--checkpoint_path` continues training from it (reference launcher.py:97-117)."""
+    into a fresh model + optimiser (`resume_optimizer=True`, Lightning's fit(ckpt_path=)) it restores
+    parameters, BOTH Adam moments and the step count bit for bit.  `--checkpoint_path` alone is the
+    reference's resume (launcher.py:97-165: weights from the file, a fresh Adam at --lr);
+    `--resume_optimizer` continues the optimiser too."""
     import glob
     import launcher
     from mri_interpolation_amd import checkpoint
@@ -312,7 +314,7 @@ def test_launcher_checkpoint_resumes_parameters_and_optimizer(amd, tmp_path):
         pytest.skip("the launcher's default --tiny_mlp encoder is not the one rebuilt here")
     net.cuda()
     opt = net.configure_optimizers()
-    checkpoint.load(files[0], net, opt, map_location="cuda")
+    checkpoint.load(files[0], net, opt, map_location="cuda", resume_optimizer=True)
     assert opt.step_count == steps
     again = checkpoint.lightning_checkpoint(net, opt, epoch=1, global_step=steps)
     for k, v in ckpt["state_dict"].items():
@@ -321,14 +323,24 @@ def test_launcher_checkpoint_resumes_parameters_and_optimizer(amd, tmp_path):
     for i, s in state.items():
         t = again["optimizer_states"][0]["state"][i]
         assert torch.equal(s["exp_avg"], t["exp_avg"]) and torch.equal(s["exp_avg_sq"], t["exp_avg_sq"]), i
-    # and the launcher resumes from it: the first logged loss of the resumed run continues the curve
+    # the launcher resumes from it.  Default = the reference: weights only, Adam restarts at step 0 with the
+    # learning rate of THIS command line; --resume_optimizer continues moments and step count (still at --lr)
     out2 = str(tmp_path / "resumed")
-    launcher.main(argv[:-4] + ["--out_dir", out2, "--log_every", "0", "--checkpoint_path", files[0]])
+    launcher.main(argv[:-4] + ["--out_dir", out2, "--log_every", "0", "--checkpoint_path", files[0],
+                               "--lr", "0.002"])
     resumed = glob.glob(os.path.join(out2, "checkpoints", "*.ckpt"))
     assert len(resumed) == 1
     r = torch.load(resumed[0], weights_only=True)
-    rs = r["optimizer_states"][0]["state"]
-    assert all(float(s["step"]) == 2 * steps for s in rs.values()), "the optimiser's step count restarted"
+    rs = r["optimizer_states"][0]
+    assert all(float(s["step"]) == steps for s in rs["state"].values()), "a fresh Adam counts from zero"
+    assert rs["param_groups"][0]["lr"] == 0.002, "--lr was ignored on resume"
+    out3 = str(tmp_path / "continued")
+    launcher.main(argv[:-4] + ["--out_dir", out3, "--log_every", "0", "--checkpoint_path", files[0],
+                               "--resume_optimizer", "--lr", "0.002"])
+    r = torch.load(glob.glob(os.path.join(out3, "checkpoints", "*.ckpt"))[0], weights_only=True)
+    rs = r["optimizer_states"][0]
+    assert all(float(s["step"]) == 2 * steps for s in rs["state"].values()), "the optimiser's step count restarted"
+    assert rs["param_groups"][0]["lr"] == 0.002
 
 
 # --------------------------------------------------------------------------- batch producer

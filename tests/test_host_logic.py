@@ -267,6 +267,30 @@ def test_entry_points_set_the_ipc_mode_before_torch_loads():
         assert seen_env, name
 
 
+def test_ipc_mode_is_defaulted_for_multi_process_launches_only(monkeypatch):
+    """A single process never touches HSA_ENABLE_IPC_MODE_LEGACY; with WORLD_SIZE > 1 it is a default
+    that an explicit setting wins over (parallel.ipc_default; bench.py / launcher.py do the same at
+    module level, before torch loads)."""
+    from mri_interpolation_amd import parallel
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    parallel.ipc_default()
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ
+    parallel.ipc_default(1)
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    parallel.ipc_default()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    parallel.ipc_default(8)
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("bench.py", "launcher.py"):
+        src = open(os.path.join(root, name)).read()
+        guard = src.index('os.environ.get("WORLD_SIZE", "1")) > 1')
+        assert guard < src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY"'), name
+
+
 @pytest.mark.parametrize("frames", [15, 14])
 def test_interp_baseline_equals_scipy_linear_interpolation(frames):
     """interp.py's counterpart (reference interp.py:35-50: even frames -> itk.LinearInterpolateImageFunction,
