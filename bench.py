@@ -14,6 +14,7 @@ Workloads (BASELINE.json configs; the metric is quoted on a 256^3 volume at 1/2/
   cfg3  256^3, SIREN 3-256x5-1, coords in [-1,1], B=2^20
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -305,8 +306,8 @@ def main():
     ap.add_argument("--phase-every", type=int, default=0,
                     help="bracket the phases with HIP events on every n-th timed step only (the 4th, the (n+4)th, "
                          "...): a timing event is a serialisation point, five per step cost 0.15 ms (0.71 against "
-                         "0.56 ms per step with n = 1, round 3).  0 (default) = max(4, steps // 5): five sampled "
-                         "steps whatever the run length (the driver's 20-step form: every 4th), so that "
+                         "0.56 ms per step with n = 1, round 3).  0 (default) = max(6, steps // 5): five sampled "
+                         "steps in a long run, three in the driver's 20-step form (steps 4, 10, 16), so that "
                          "phases_ms / rooflines.*.ms_per_launch are means of >= 3 launches")
     ap.add_argument("--launch", default="native", choices=["native", "graph", "eager"],
                     help="how a step is queued (trainer.SteadyLoop): native = one mri_fused_step call per step; "
@@ -349,7 +350,7 @@ def main():
                     help="level groups of the table-gradient kernels (0 = default)")
     args = ap.parse_args()
     if args.phase_every <= 0:
-        args.phase_every = max(4, args.steps // 5)
+        args.phase_every = max(6, args.steps // 5)
 
     import torch
     from mri_interpolation_amd import _lib, datamodules, parallel, trainer
@@ -467,17 +468,32 @@ def main():
         for _ in range(warmup):
             one_step()
         sampling[0], leg_start[0] = True, counter[0]
+        if graphed[0] is not None and hasattr(graphed[0], "reserve_samples"):
+            graphed[0].reserve_samples(steps // max(1, args.phase_every) + 1)  # no event is created inside the timed region
+        # Python's cyclic collector stays out of the timed region: a FULL collection (every object of the process:
+        # torch alone brings millions) takes 40-58 ms here, and the allocation counts that trigger it are
+        # deterministic -- in the 40-step form it fell on step 24 of every run, 1.3 ms per step instead of 0.51
+        # (round 4, tools/stall_probe.py; MRI_STEP_TIMES=1 prints the host time of every queued step)
+        gc.collect()
+        gc.disable()
         parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        trace = [] if os.environ.get("MRI_STEP_TIMES") else None  # diagnostic: host time of every queued step
         for _ in range(steps):
+            t_step = time.perf_counter()
             loss = one_step()
+            if trace is not None:
+                trace.append(round((time.perf_counter() - t_step) * 1e3, 3))
+        if trace is not None:
+            print("host ms per queued step:", trace, file=sys.stderr)
         host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to QUEUE a step (host side)
         if graphed[0] is not None:
             graphed[0].finish()
         torch.cuda.synchronize()
         parallel.barrier()
         elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+        gc.enable()
         step.phase_events = events
         phases = step.phase_ms()
         n_samples = min((len(v) for v in events.values()), default=0)

@@ -76,7 +76,8 @@ constexpr int kAccThreads = MRI_ACC_THREADS;
 #define MRI_BIN_THREADS 512
 #endif
 constexpr int kBinThreads = MRI_BIN_THREADS;
-constexpr int kStageWords = 24 * kBinThreads;  // LDS staging buffer of the scatter kernel: 48 KiB, 2 workgroups/CU
+constexpr int kStageWords = 24 * kBinThreads;  // LDS staging buffer of the scatter kernel: 48 KiB, 3 workgroups/CU
+constexpr int kPackedStageWords = 18 * kBinThreads;  // ... with packed 8-byte records: 4608 of them
 constexpr int kMaxParts = 256;        // slices per level handled by the binned path
 constexpr int kHeaderWords = 64;      // per-level max|g| bits
 constexpr int kMaxBins = MRI_MAX_LEVELS * kMaxParts;
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   __shared__ uint32_t hist[kMaxParts];      // contributions of this workgroup per bin
   __shared__ uint32_t local_off[kMaxParts + 1];
   __shared__ uint32_t global_base[kMaxParts];
-  // (packed records: 8 instead of 12 bytes per corner -> 32 KiB, four workgroups per CU)
-  __shared__ __attribute__((aligned(16))) uint32_t stage[SCATTER ? (R == kRecPacked ? kStageWords * 2 / 3 : kStageWords) : 1];
+  // (packed records: 8 instead of 12 bytes per corner, room for an eighth more -> 36 KiB, four workgroups per CU)
+  __shared__ __attribute__((aligned(16))) uint32_t stage[SCATTER ? (R == kRecPacked ? kPackedStageWords : kStageWords) : 1];
   __shared__ uint32_t wg_max;
 
   const int e = blockIdx.y;
@@ -299,13 +300,32 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
       uint32_t h0[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) h0[d] = cell_low32(x[i * D + d] * res[d]) * kPrimes[d];
+      if constexpr (F == 2) {
+        // PAIRS (see the scatter below): the two corners that differ on axis 0 are routed together, two
+        // record positions per pair -- in ONE bin when both slots lie in the same slice (always, unless
+        // the axis-0 cell index ends in log2_slots ones or the wrap of `% T` falls between them), else
+        // two positions in EACH of the two bins (a record and a zero pad)
 #pragma unroll
-      for (int q = 0; q < G::corners; ++q) {
-        const int nb = sub * G::corners + q;
-        uint32_t h = 0;
+        for (int q = 0; q < G::corners; q += 2) {
+          const int nb = sub * G::corners + q;
+          uint32_t ha = h0[0];
 #pragma unroll
-        for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
-        atomicAdd(&hist[slot_of(h, size, magic, pow2) >> plan.log2_slots], 1u);
+          for (int d = 1; d < D; ++d) ha ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
+          const uint32_t hb = ha ^ h0[0] ^ (h0[0] + 1u);  // kPrimes[0] = 1
+          const uint32_t pa = slot_of(ha, size, magic, pow2) >> plan.log2_slots;
+          const uint32_t pb = slot_of(hb, size, magic, pow2) >> plan.log2_slots;
+          atomicAdd(&hist[pa], 2u);
+          if (pb != pa) atomicAdd(&hist[pb], 2u);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < G::corners; ++q) {
+          const int nb = sub * G::corners + q;
+          uint32_t h = 0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) h ^= ((nb >> d) & 1) ? h0[d] + kPrimes[d] : h0[d];
+          atomicAdd(&hist[slot_of(h, size, magic, pow2) >> plan.log2_slots], 1u);
+        }
       }
     }
     __syncthreads();
@@ -346,38 +366,136 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
   // pass B: recompute the corners and stage (slot in slice, w * g[f]) grouped by bin
   const uint32_t total = local_off[parts];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if constexpr (R == kRecPacked) {
-    // one 8-byte word per record (pack_record): one scattered LDS store here, one read and ONE global
-    // store in the copy-out, one load in the accumulate kernel -- a third of the 2 + 4 + 4-byte form's
-    // LDS conflict cycles and store instructions, which is where this kernel's time goes (4.2)
-    const uint32_t mb = max_bits[level];  // complete: level_absmax ran before this kernel
+  if constexpr (F == 2) {
+    // Two features per level: the two corners that differ on axis 0 (PRIME_0 = 1: their slots differ in the
+    // low bits only) are routed as a PAIR -- one bin lookup, one LDS counter atomic, one slot word and two
+    // 8-byte value stores per pair instead of two atomics and six 4-byte stores, and half as many, twice
+    // as wide stores in the copy-out.  A pair occupies two ADJACENT record positions, so the record
+    // area holds exactly what it held before (slot16[2], val[f][2]) and the accumulate kernel reads it
+    // unchanged; the sums are the same integers, the gradient bit-identical.  A pair whose slots lie in
+    // two slices (axis-0 cell ending in log2_slots ones, cell -1, or the wrap of `% T` between them:
+    // 0.1 % of the pairs of a non-power-of-two level, none of a power-of-two level of BASELINE's grids)
+    // leaves a record and a zero pad in each of the two bins: the count stage reserved both.
+    const uint32_t mb = R == kRecPacked ? max_bits[level] : 0u;  // (complete: level_absmax ran before this kernel)
     const int E = level_E(mb), es0 = rec_exponent(mb);
-    uint2* __restrict__ stage2 = reinterpret_cast<uint2*>(stage);
-    if (live) {
+    // staging capacity in records: the usual 2^D per coordinate plus a sixth for pads; a workgroup beyond
+    // it (a batch of coordinates outside the grid) writes its records straight to HBM
+    constexpr uint32_t kCap = R == kRecPacked ? kPackedStageWords / 2 : kStageWords / 5 * 2 - 2;
+    const bool staged = total <= kCap;
+    // f32 records, staged per PAIR position pp = record position / 2: slot word | v[0] pair | v[1] pair
+    const uint32_t pairs = total >> 1, pairs_even = (pairs + 1u) & ~1u;
+    uint32_t* __restrict__ st_slot = stage;
+    float2* __restrict__ st_v0 = reinterpret_cast<float2*>(stage + pairs_even);
+    float2* __restrict__ st_v1 = reinterpret_cast<float2*>(stage + pairs_even + 2 * pairs);
+    uint2* __restrict__ stage2 = reinterpret_cast<uint2*>(stage);  // packed records, per record position
+    uint32_t* __restrict__ out_slot = reinterpret_cast<uint32_t*>(rec_slot);  // record area, per pair position
+    float2* __restrict__ out_v0 = reinterpret_cast<float2*>(rec_val);
+    float2* __restrict__ out_v1 = reinterpret_cast<float2*>(rec_val + records);  // (`records` is a multiple of 4)
+    uint2* __restrict__ out_rec = reinterpret_cast<uint2*>(rec_val);
+    // bin id in the spare bits of the staged slot word (13-bit slots): the copy-out then walks the staging
+    // buffer linearly, every lane busy; levels with more than 64 slices copy out bin by bin
+    const bool flat = plan.log2_slots <= 13 && parts <= 64;
+    float gmax = 0.0f;
+    if (live) gmax = fmaxf(fabsf(g[0]), fabsf(g[1]));
+    if (R != kRecPacked && max_bits != nullptr) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
+      // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
+      // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
+      if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
+    }
+    // (two instantiations of the loop, staged and straight to HBM: with one loop and a run-time choice of the
+    // destination hipcc selects between an LDS and a global pointer through scratch and stores with flat_store)
+    auto route = [&](auto staged_tag) {
+      constexpr bool STAGED = decltype(staged_tag)::value;
+      auto emit = [&](uint32_t p, uint32_t sa, uint32_t sb, float a0, float a1, float b0, float b1) {
+        const uint32_t r = atomicAdd(&hist[p], 2u);  // (even: every add is 2)
+        if constexpr (R == kRecPacked) {
+          const uint2 ra = pack_record(sa, a0, a1, E, es0), rb = pack_record(sb, b0, b1, E, es0);
+          if constexpr (STAGED) {
+            stage2[local_off[p] + r] = ra, stage2[local_off[p] + r + 1] = rb;
+          } else {
+            out_rec[(uint64_t)global_base[p] + r] = ra, out_rec[(uint64_t)global_base[p] + r + 1] = rb;
+          }
+        } else {
+          const uint32_t word = sa | (sb << 16);
+          if constexpr (STAGED) {
+            const uint32_t pp = (local_off[p] + r) >> 1;
+            st_slot[pp] = flat ? word | ((p & 7u) << 13) | ((p >> 3) << 29) : word;
+            st_v0[pp] = make_float2(a0, b0);
+            st_v1[pp] = make_float2(a1, b1);
+          } else {
+            const uint64_t pp = ((uint64_t)global_base[p] + r) >> 1;
+            out_slot[pp] = word;
+            out_v0[pp] = make_float2(a0, b0);
+            out_v1[pp] = make_float2(a1, b1);
+          }
+        }
+      };
       const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
-      for (int q = 0; q < G::corners; ++q) {
-        uint32_t h;
-        float w;
-        corner<D>(c, sub * G::corners + q, h, w);
-        const uint32_t slot = slot_of(h, size, magic, pow2);
-        const uint32_t p = slot >> plan.log2_slots;
-        const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
-        stage2[pos] = pack_record(slot & slot_mask, g[0] * w, g[1] * w, E, es0);
+      for (int q = 0; q < G::corners; q += 2) {
+        const int nb = sub * G::corners + q;
+        uint32_t ha, hb;
+        float wa, wb;
+        corner<D>(c, nb, ha, wa);
+        corner<D>(c, nb + 1, hb, wb);
+        const uint32_t sa = slot_of(ha, size, magic, pow2), sb = slot_of(hb, size, magic, pow2);
+        const uint32_t pa = sa >> plan.log2_slots, pb = sb >> plan.log2_slots;
+        const float a0 = g[0] * wa, a1 = g[1] * wa, b0 = g[0] * wb, b1 = g[1] * wb;
+        if (pa == pb) {
+          emit(pa, sa & slot_mask, sb & slot_mask, a0, a1, b0, b1);
+        } else {  // (rare, see above) a record and a zero pad on its own slot in each bin
+          emit(pa, sa & slot_mask, sa & slot_mask, a0, a1, 0.0f, 0.0f);
+          emit(pb, sb & slot_mask, sb & slot_mask, b0, b1, 0.0f, 0.0f);
+        }
       }
+    };
+    if (live) {
+      if (staged)
+        route(std::true_type{});
+      else
+        route(std::false_type{});
     }
     __syncthreads();
     BWDP(4)
-    // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous 8-byte stores
-    uint2* __restrict__ rec = reinterpret_cast<uint2*>(rec_val);
-    for (int p = wave; p < parts; p += kBinThreads / 64) {
-      const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
-      const uint64_t dst = (uint64_t)global_base[p];
-      for (uint32_t k = lane; k < cnt; k += 64) rec[dst + k] = stage2[lo + k];
+    if (R != kRecPacked && max_bits != nullptr && threadIdx.x == 0 &&
+        wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(max_bits + level, wg_max);
+    if (staged) {
+      if constexpr (R == kRecPacked) {
+        // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous 8-byte stores
+        for (int p = wave; p < parts; p += kBinThreads / 64) {
+          const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+          const uint64_t dst = (uint64_t)global_base[p];
+          for (uint32_t k = lane; k < cnt; k += 64) out_rec[dst + k] = stage2[lo + k];
+        }
+      } else if (flat) {
+        // linear over the staging buffer: lane k copies pair k, its bin is in the slot word
+        for (uint32_t k = threadIdx.x; k < pairs; k += kBinThreads) {
+          const uint32_t word = st_slot[k];
+          const float2 v0 = st_v0[k], v1 = st_v1[k];
+          const uint32_t p = ((word >> 13) & 7u) | ((word >> 29) << 3);
+          const uint64_t dst = ((uint64_t)global_base[p] >> 1) + (k - (local_off[p] >> 1));
+          out_slot[dst] = word & 0x1fff1fffu;
+          out_v0[dst] = v0;
+          out_v1[dst] = v1;
+        }
+      } else {
+        for (int p = wave; p < parts; p += kBinThreads / 64) {
+          const uint32_t lo = local_off[p] >> 1, cnt = (local_off[p + 1] >> 1) - lo;
+          const uint64_t dst = (uint64_t)global_base[p] >> 1;
+          for (uint32_t k = lane; k < cnt; k += 64) {
+            out_slot[dst + k] = st_slot[lo + k];
+            out_v0[dst + k] = st_v0[lo + k];
+            out_v1[dst + k] = st_v1[lo + k];
+          }
+        }
+      }
     }
   } else {
-    // f32 records.  max |g| seen by this thread feeds the level's fixed-point scale, which only the
-    // accumulate launch needs -- unless the caller supplied the maxima (max_bits == nullptr here)
+    // other feature counts: one record per corner, 16-bit slot + F f32 values in F + 1 arrays.  max |g|
+    // seen by this thread feeds the level's fixed-point scale, which only the accumulate launch needs
     float gmax = 0.0f;
     if (live) {
 #pragma unroll
@@ -386,43 +504,38 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     if (max_bits != nullptr) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, 64));
-      // non-negative floats order like their bit patterns; one atomic per workgroup, and only if
-      // it can still raise the level's maximum (thousands of workgroups share 16 addresses)
       if ((threadIdx.x & 63) == 0) atomicMax(&wg_max, __float_as_uint(gmax));
     }
-    {
-      if (live) {
-        const Cell<D> c = locate<D>(xi, 0, res);
+    if (live) {
+      const Cell<D> c = locate<D>(xi, 0, res);
 #pragma unroll
-        for (int q = 0; q < G::corners; ++q) {
-          const int nb = sub * G::corners + q;
-          uint32_t h;
-          float w;
-          corner<D>(c, nb, h, w);
-          const uint32_t slot = slot_of(h, size, magic, pow2);
-          const uint32_t p = slot >> plan.log2_slots;
-          const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
-          stage[pos] = slot & slot_mask;
+      for (int q = 0; q < G::corners; ++q) {
+        const int nb = sub * G::corners + q;
+        uint32_t h;
+        float w;
+        corner<D>(c, nb, h, w);
+        const uint32_t slot = slot_of(h, size, magic, pow2);
+        const uint32_t p = slot >> plan.log2_slots;
+        const uint32_t pos = local_off[p] + atomicAdd(&hist[p], 1u);
+        stage[pos] = slot & slot_mask;
 #pragma unroll
-          for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
-        }
+        for (int f = 0; f < F; ++f) stage[(1 + f) * total + pos] = __float_as_uint(g[f] * w);
       }
-      __syncthreads();
-      BWDP(4)
-      if (max_bits != nullptr && threadIdx.x == 0 &&
-          wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(max_bits + level, wg_max);
-
-      // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
-      for (int p = wave; p < parts; p += kBinThreads / 64) {
-        const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
-        const uint64_t dst = (uint64_t)global_base[p];
-        for (uint32_t k = lane; k < cnt; k += 64) {
-          rec_slot[dst + k] = (uint16_t)stage[lo + k];
+    }
+    __syncthreads();
+    BWDP(4)
+    if (max_bits != nullptr && threadIdx.x == 0 &&
+        wg_max > __hip_atomic_load(max_bits + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(max_bits + level, wg_max);
+    // copy out: each wave takes whole bins, lanes walk a bin's run -> contiguous global stores
+    for (int p = wave; p < parts; p += kBinThreads / 64) {
+      const uint32_t lo = local_off[p], cnt = local_off[p + 1] - lo;
+      const uint64_t dst = (uint64_t)global_base[p];
+      for (uint32_t k = lane; k < cnt; k += 64) {
+        rec_slot[dst + k] = (uint16_t)stage[lo + k];
 #pragma unroll
-          for (int f = 0; f < F; ++f)
-            rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
-        }
+        for (int f = 0; f < F; ++f)
+          rec_val[(uint64_t)f * records + dst + k] = __uint_as_float(stage[(1 + f) * total + lo + k]);
       }
     }
   }
@@ -964,7 +1077,9 @@ bool make_plan(const mri_grid_desc* g, int64_t n, int method, BinPlan& plan, Bin
       plan.ws_offset[e] = ws_words;
       ws_words += (int64_t)g->table_size[l] * F;
     }
-    records += n << D;
+    // two features per level: pairs whose slots lie in two slices leave a pad in each (bin_kernel); every
+    // pair of a batch can be one (coordinates one cell outside the grid on axis 0), so room for twice the corners
+    records += (n << D) * (F == 2 ? 2 : 1);
   }
   // Dense levels: every workgroup hashes ALL corners of its coordinate range and keeps those of
   // its slice, so a workgroup's time is set by the length of that range alone: one range length

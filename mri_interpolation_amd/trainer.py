@@ -15,6 +15,7 @@ Other models (e.g. the BatchNorm decoder) run `training_step` + autograd, op by 
 """
 import contextlib
 import ctypes as C
+import os
 import time
 from typing import Dict, List, Optional
 
@@ -602,6 +603,9 @@ class FusedStep:
             self._batch_event = None
         if self.encoder is not None and self.overlap_count and self.bwd_method != 1:
             if self._side is None:
+                # (stream priorities, measured in round 4: this runtime offers 0 and -1 only; the main stream on -1
+                # delays the side work until it lands beside the table gradient: lookup -2 us, table gradient
+                # +10 us, step unchanged.  Both streams stay at the default priority.)
                 self._side = torch.cuda.Stream(device=coords.device)
             # after the coordinates exist and after the previous step's backward released its
             # workspace and batch buffer (all earlier work of the current stream)
@@ -732,7 +736,13 @@ class SteadyLoop:
     bit-identical (tests/test_gpu_round3.py::test_steady_loop_equals_the_eager_loop).
 
     Eager steps (bench.py's event-bracketed sample steps, evaluation passes) can be mixed in: the Python
-    state of FusedStep / BatchPipeline / Adam is advanced as the eager step would have left it."""
+    state of FusedStep / BatchPipeline / Adam is advanced as the eager step would have left it.  Two limits:
+    (1) the native argument blocks hold raw device addresses of FusedStep's buffers; an eager step with ANOTHER
+    batch size makes FusedStep reallocate them -- step_once() detects that and raises (capture() again);
+    (2) after a natively queued step `flat.grad` does NOT hold the table gradient of the levels whose sums meet
+    in the int64 workspace (the dense levels, bins cut over entry ranges): their conversion is folded into the
+    Adam kernel (csrc/fused_step.hip), which consumes them straight from the workspace.  Readers of `.grad`
+    (gradient clipping, logging) must take an eager step, whose table gradient is complete in `flat.grad`."""
 
     @staticmethod
     def unsupported(step: "FusedStep", pipe: BatchPipeline) -> Optional[str]:
@@ -855,8 +865,29 @@ class SteadyLoop:
             a.order_ws, a.order_ws_bytes = ptr(self.pipe._order_ws), self.pipe._order_ws.numel() * 8
         a.stream_side = st._side.cuda_stream
         a.ev_fork, a.ev_join = self._ev_fork.cuda_event, self._ev_join.cuda_event
-        self._keep = getattr(self, "_keep", []) + [tiny_ws]  # (the struct holds raw pointers only)
+        # The struct holds RAW pointers: every tensor behind one is pinned here (kept alive) with the address it
+        # had, and step_once() refuses to queue through a block whose tensors have moved -- FusedStep evicts
+        # its per-size workspaces (`_workspace`: one size kept) and regrows `_bwd_ws` when an eager step with
+        # another batch size runs in between, which would otherwise leave the block writing through stale addresses.
+        pins = dict(enc=w["enc"], d_enc=w["d_enc"], tiny_ws=tiny_ws, ws_p=ws_p, ws_q=ws_q, table_grad=st._table_grad,
+                    param=f.param, grad=f.grad, exp_avg=f.exp_avg, exp_avg_sq=f.exp_avg_sq, coords_p=coords_p,
+                    coords_q=coords_q, idx_q=idx_q)
+        if am_p is not None:
+            pins.update(absmax_p=am_p, absmax_q=am_q)
+        self._pins[p] = [(name, t, t.data_ptr()) for name, t in pins.items()]
         return a
+
+    def _check_pins(self, p: int):
+        st = self.step
+        n = self.pipe.loader.batch_size
+        live = dict(enc=st._ws.get((n, True), {}).get("enc"), d_enc=st._ws.get((n, True), {}).get("d_enc"),
+                    ws_p=st._bwd_ws[self._wmap[p]], ws_q=st._bwd_ws[self._wmap[1 - p]], table_grad=st._table_grad,
+                    param=st.flat.param, grad=st.flat.grad)
+        for name, t, addr in self._pins[p]:
+            now = live.get(name, t)
+            if now is None or now.data_ptr() != addr:
+                raise RuntimeError(f"SteadyLoop: the {name} buffer of FusedStep moved since capture() (an eager step "
+                                   "with another batch size ran in between?): call capture() again")
 
     def capture(self, warm_steps: int = 4):
         """`warm_steps` eager steps (at least two before the first capture: they allocate every workspace and
@@ -892,7 +923,7 @@ class SteadyLoop:
             self._ev_fork.record()  # materialises the handles
             self._ev_join.record()
             torch.cuda.synchronize()
-            self._keep = []
+            self._pins = [None, None]
             self._args = [self._native_args(0), self._native_args(1)]
         self._after_eager, self._join_pending = True, False
         return self
@@ -909,6 +940,18 @@ class SteadyLoop:
         return loss
 
     PHASES = ("hashgrid_fwd", "mlp_fused", "hashgrid_bwd", "adam")
+
+    def reserve_samples(self, n: int):
+        """Create and materialise the timing events of `n` sampled steps NOW, outside the timed region: creating
+        a timing event and recording it for the first time inside a deep queue stalled the host for milliseconds
+        on some boxes (bench.py's 20-step form with five sampled steps: 2-4 ms per step instead of 0.52)."""
+        pool = getattr(self, "_event_pool", [])
+        while len(pool) < n:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            for ev in evs:
+                ev.record()  # materialises the handle (re-recorded inside the library call)
+            pool.append(evs)
+        self._event_pool = pool
 
     def step_once(self, sample: bool = False):
         """Queue the current step; returns the (device) loss scalar.  `sample` (native mode): bracket the four
@@ -942,15 +985,21 @@ class SteadyLoop:
             self.graphs[p].replay()
         else:
             a = self._args[p]
+            self._check_pins(p)
             a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
             a.lr = opt.param_groups[0]["lr"]
             a.join_pending = 1 if self._join_pending else 0
             a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
             evs = None
             if sample and st.phase_events is not None:
-                evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                pool = getattr(self, "_event_pool", None)
+                if pool:
+                    evs = pool.pop()
+                else:
+                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                    for ev in evs:
+                        ev.record()  # materialises the handle (re-recorded inside the call)
                 for i, ev in enumerate(evs):
-                    ev.record()  # materialises the handle (re-recorded inside the call)
                     a.ev_phase[i] = ev.cuda_event
             _lib.call("mri_fused_step", C.byref(a))
             if evs is not None:

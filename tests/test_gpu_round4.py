@@ -11,12 +11,25 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REL_TOL, assert_close, load_golden, rel_err
+from conftest import REL_TOL, load_golden
 from oracle import detrand
 from oracle import hashgrid as ohash
 from oracle import mlp as omlp
 
 pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    """conftest.rel_err without its 1e-30 floor on the denominators: the tensors of this file live at 2^-100
+    (7.9e-31) and below, where that floor would hide a factor; the reference must not vanish instead."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape and np.abs(b).max() > 0.0
+    return np.abs(a - b).max() / np.abs(b).max(), np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def assert_close(a, b, tol=REL_TOL, what=""):
+    e_max, e_l2 = rel_err(a, b)
+    assert e_max <= tol and e_l2 <= tol, f"{what}: rel-to-max {e_max:.3e}, rel-L2 {e_l2:.3e} > {tol}"
 
 
 @pytest.fixture(scope="module")
@@ -193,3 +206,70 @@ def test_where_the_three_term_split_stops_being_exact(amd, capsys):
     with capsys.disabled():
         print("\nthree-term product, decoder forward, operands scaled by 2^s: "
               + ", ".join(f"s={s}: {a:.1e}" for s, a, _ in report))
+
+
+# ----------------------------------------------------------------------- table gradient: records routed as pairs
+def _table_gradient_case(amd, dim, resolutions, sizes, x, seed, records):
+    """Binned table gradient (method 2, records f32 or packed) of an F = 2 grid against the float64 yardstick
+    and the global-atomic kernel; returns the binned result."""
+    n_levels = len(sizes)
+    desc = amd.ops.make_grid_desc(dim, resolutions, sizes, 2)
+    n = x.shape[0]
+    d_out = torch.from_numpy(detrand.uniform(n * n_levels * 2, seed, -1, 1).reshape(n, n_levels * 2))
+    want = ohash.table_gradient_f64(x, d_out, sizes, resolutions, 2)
+    rows = sum(sizes)
+    amd.lib.set_option("bwd_records", records)
+    try:
+        got = amd.ops.hashgrid_backward(desc, x.cuda(), d_out.cuda(), torch.zeros(rows, 2, device="cuda"), method=2)
+        again = amd.ops.hashgrid_backward(desc, x.cuda(), d_out.cuda(), torch.zeros(rows, 2, device="cuda"), method=2)
+    finally:
+        amd.lib.set_option("bwd_records", 0)
+    atomic = amd.ops.hashgrid_backward(desc, x.cuda(), d_out.cuda(), torch.zeros(rows, 2, device="cuda"), method=1)
+    assert torch.equal(got, again), "the binned table gradient is bitwise reproducible"
+    off = 0
+    for l, (total, mag, count) in enumerate(want):
+        g = got[off:off + sizes[l]].double().cpu()
+        bound = (2.0 ** -24 if records == 0 else 2.0 ** -17) * (mag + total.abs()) + 1e-30
+        assert bool(((g - total).abs() <= bound + 2.0 ** -40 * mag.max()).all()), f"level {l}: a slot misses its bound"
+        assert bool((g[count == 0] == 0).all()), f"level {l}: a slot nothing hashes to holds a gradient"
+        assert_close(atomic[off:off + sizes[l]].cpu().numpy(), total.numpy(), REL_TOL, f"atomic level {l}")
+        off += sizes[l]
+    return got
+
+
+@pytest.mark.parametrize("records", [0, 1])
+def test_pair_routing_where_the_two_slots_lie_in_different_slices(amd, records):
+    """The table gradient routes the two corners that differ on axis 0 as ONE pair (hashgrid_bwd.hip).  Their slots
+    lie in the same 8192-slot slice unless the axis-0 cell index ends in thirteen ones, the cell is -1 (0xFFFFFFFF
+    -> 0), or the wrap of `% T` falls between them; then each bin gets a record and a zero pad.  Cases: a grid of
+    resolution 20000 queried around cell 8191 / 16383; coordinates one cell outside the grid on axis 0 (every pair
+    splits: twice the records, the workgroups write straight to HBM); a non-power-of-two table; D = 2 ... 4."""
+    rng = np.random.default_rng(5)
+    # (a) D = 3, T = 2^19 (64 slices), cells 8190 .. 8192 and 16382 .. 16384 on axis 0
+    n = 3000
+    x = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    x[: n // 2, 0] = ((8190 + rng.uniform(0, 3, n // 2)) / 20000.0).astype(np.float32)
+    x[n // 2:, 0] = ((16382 + rng.uniform(0, 3, n - n // 2)) / 20000.0).astype(np.float32)
+    _table_gradient_case(amd, 3, [[20000.0] * 3], [1 << 19], torch.from_numpy(x), 11, records)
+    # (b) every coordinate in cell -1 of axis 0 on the first level (pos in (-1.95, -1.05) truncates toward zero to -1:
+    # "floor" vertex 0xFFFFFFFF, upper vertex 0 -- every pair splits), cells -1 .. -3 on the second
+    for dim in (2, 3, 4):
+        n = 5000
+        x = rng.uniform(0, 1, (n, dim)).astype(np.float32)
+        x[:, 0] = (-(1.0 + rng.uniform(0.05, 0.95, n)) / 64.0).astype(np.float32)
+        _table_gradient_case(amd, dim, [[64.0] * dim, [100.0] * dim], [1 << 17, 1 << 17], torch.from_numpy(x), 12 + dim,
+                             records)
+    # (c) non-power-of-two tables (true `% T`): pairs around the wrap; a mix of inside / outside coordinates
+    n = 20000
+    x = rng.uniform(-0.2, 1.2, (n, 3)).astype(np.float32)
+    _table_gradient_case(amd, 3, [[61.0] * 3, [86.0] * 3, [330.0] * 3], [226981, 300763, 328509], torch.from_numpy(x), 21,
+                         records)
+
+
+def test_pair_routing_with_more_than_64_slices(amd):
+    """T = 2^20 and 2^21: 128 / 256 slices per level -- the copy-out goes bin by bin (the slot word has room for a
+    6-bit bin id only) -- beside a 2^19 level that takes the linear copy-out, in one call."""
+    rng = np.random.default_rng(6)
+    n = 30000
+    x = torch.from_numpy(rng.uniform(0, 1, (n, 3)).astype(np.float32))
+    _table_gradient_case(amd, 3, [[512.0] * 3, [700.0] * 3, [900.0] * 3], [1 << 19, 1 << 20, 1 << 21], x, 31, 0)
