@@ -392,9 +392,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
     float2* __restrict__ out_v0 = reinterpret_cast<float2*>(rec_val);
     float2* __restrict__ out_v1 = reinterpret_cast<float2*>(rec_val + records);  // (`records` is a multiple of 4)
     uint2* __restrict__ out_rec = reinterpret_cast<uint2*>(rec_val);
-    // bin id in the spare bits of the staged slot word (13-bit slots): the copy-out then walks the staging
-    // buffer linearly, every lane busy; levels with more than 64 slices copy out bin by bin
-    const bool flat = plan.log2_slots <= 13 && parts <= 64;
+    // bin id in the spare bits of the staged slot word (two 16-bit halves holding log2_slots-bit slots): the
+    // copy-out then walks the staging buffer linearly, every lane busy; a level with more slices than the
+    // spare bits can name (64 for 13-bit slots) copies out bin by bin
+    const int spare = 16 - plan.log2_slots;  // per half
+    const bool flat = spare >= 1 && parts <= (1 << (2 * spare));
+    const uint32_t half_mask = (1u << plan.log2_slots) - 1u, spare_mask = (1u << spare) - 1u;
     float gmax = 0.0f;
     if (live) gmax = fmaxf(fabsf(g[0]), fabsf(g[1]));
     if (R != kRecPacked && max_bits != nullptr) {
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
           const uint32_t word = sa | (sb << 16);
           if constexpr (STAGED) {
             const uint32_t pp = (local_off[p] + r) >> 1;
-            st_slot[pp] = flat ? word | ((p & 7u) << 13) | ((p >> 3) << 29) : word;
+            st_slot[pp] = flat ? word | ((p & spare_mask) << plan.log2_slots) | ((p >> spare) << (16 + plan.log2_slots))
+                               : word;
             st_v0[pp] = make_float2(a0, b0);
             st_v1[pp] = make_float2(a1, b1);
           } else {
@@ -475,9 +479,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_kernel(
         for (uint32_t k = threadIdx.x; k < pairs; k += kBinThreads) {
           const uint32_t word = st_slot[k];
           const float2 v0 = st_v0[k], v1 = st_v1[k];
-          const uint32_t p = ((word >> 13) & 7u) | ((word >> 29) << 3);
+          const uint32_t p = ((word >> plan.log2_slots) & spare_mask) | ((word >> (16 + plan.log2_slots)) << spare);
           const uint64_t dst = ((uint64_t)global_base[p] >> 1) + (k - (local_off[p] >> 1));
-          out_slot[dst] = word & 0x1fff1fffu;
+          out_slot[dst] = word & (half_mask * 0x10001u);
           out_v0[dst] = v0;
           out_v1[dst] = v1;
         }
