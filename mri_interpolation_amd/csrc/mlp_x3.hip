@@ -80,25 +80,18 @@ constexpr int kX3ProfSlots = 32;
 #define X3P_END
 #endif
 
-// ONE (training, H = 128, 8 waves, features from HBM): dz2 is never an LDS image, see the kernel's S5 / S6.
-template <bool GATHER, bool ONE>
 struct __attribute__((aligned(16))) X3Smem {
   char x[2][3][kImg32Bytes];  // input tile, double-buffered (the next tile is staged during S7)
   char h1[3][kImgBytes];
-  char z2[ONE ? 1 : 3][ONE ? 16 : kImgBytes];  // dLoss / d(pre-activation 2)  (ONE: a bit image and two tables instead)
+  char z2[3][kImgBytes];      // dLoss / d(pre-activation 2)
   char z1[3][kImgBytes];      // dLoss / d(pre-activation 1)
   char w1[3][4 * kImg32Bytes];  // W1: [hidden unit][input feature]: A operand of layer 1 (row reads) and of dx (transposed)
   char w2l[4 * kImgBytes];      // the smallest term of W2 [out][in]: read row-wise (layer 2) and transposed (dz1)
-  char w2pl[ONE ? 4 * kImgBytes : 16];  // ONE: the smallest term of W2' = w3[out] W2[out][in] / 2, read transposed (dz1)
-  uint32_t lutk[ONE ? 256 : 1][4];      // byte -> four dwords: bf16 pair (2 q, 2 q + 1) kept (0xffff) or cleared per bit
-  uint32_t lut2[ONE ? 256 : 1][4];      // byte -> four dwords: bf16 2.0 (0x4000) or 0 per bit
-  char maskimg[ONE ? kX3Rows : 1][16];  // [row][unit / 8]: bit (unit & 7) = h2[row][unit] > 0
-  float dd[kX3Rows];                    // ONE: dLoss/dy of the tile (every wave writes the same values, reads its own)
   float ypart[8][kX3Rows];
   float tgt[2][kX3Rows];
   float b1[kX3H], b2[kX3H], w3[kX3H];  // read per tile (registers are the scarce resource here)
-  float gc[GATHER ? 2 : 1][GATHER ? kX3Rows : 1][4];  // gather mode: coordinates of the next two tiles
-  float pa[GATHER ? kX3Threads : 1][2];               // gather mode: a thread's partial sums, parked between two segments
+  float gc[2][kX3Rows][4];             // gather mode: coordinates of the next two tiles
+  float pa[kX3Threads][2];             // gather mode: a thread's partial sums, parked between two segments
   uint32_t dxmax[16];                  // max |dx| per feature pair (bit patterns), a.dx_absmax
 };
 
@@ -141,23 +134,13 @@ __device__ __forceinline__ float sum_groups(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-template <bool TRAIN, int U, int H, int GD = 0, bool ONE_OK = true>
+template <bool TRAIN, int U, int H, int GD = 0>
 __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const FusedArgs a, const EncodeArgs e) {
   // GD > 0 (gather mode, training, U = 1): the input features are looked up in the GD-dimensional hash
   // grid `e` by the thread that stages them -- thread (row tid & 31, level tid >> 5) of the staging map
   // below owns exactly one (coordinate, level) pair and its two features -- see "gather mode" below.
   constexpr bool GATHER = GD > 0;
   static_assert(!GATHER || (TRAIN && U == 1), "gather mode: the 8-wave training kernel");
-  // ONE (round 4): dz2[r][u] = d_r w3_u [h2[r][u] > 0] is never written as a three-term image.  Its two consumers take
-  //   dz1[r][j] = d_r * sum_u [h2[r][u] > 0] (w3_u W2[u][j]):  the B operand is a ONE-term 0 / 2.0 pattern looked up
-  //       from a bit image (a byte per 8 units) -- THREE bf16 MFMAs per step instead of six -- against W2' = w3 W2 / 2
-  //       split once per launch; d_r multiplies the sum in the epilogue;
-  //   dW2[u][k] = w3_u * sum_r (d_r [h2[r][u] > 0]) h1[r][k]:  the A operand (the wave's own units) is the split of d
-  //       masked by wave ballots; w3_u multiplies the sum once, at the end of the launch.
-  // The reference rounds d_r w3_u first and multiplies then (autograd of models.py:46-66); both are f32 evaluations
-  // of the same sums, held to the same 1e-5 by the parity tests.  The 24 KiB image, its stores and 30 of its reads per
-  // wave and tile go; the table of W2''s third term takes its place in LDS.
-  constexpr bool ONE = ONE_OK && TRAIN && H == 128 && U == 1 && !GATHER;
   // U = strips of 16 hidden units per wave: 1 -> 8 waves (two per SIMD, 256 registers each),
   // 2 -> 4 waves (one per SIMD, 512 registers; every activation fragment feeds two strips).
   // H = 128: wave w owns strip w (U = 1) for both 16-row halves of the tile.  H = 64 (U = 1): four
@@ -172,8 +155,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   constexpr int TL = H == 128 ? 2 : 1;             // row halves of the tile a wave works on
   constexpr int YS = H == 128 ? WAVES : 4;         // y shares per row
   constexpr int IMG = kImgBytes, IMG32 = kImg32Bytes;
-  using Smem = X3Smem<GATHER, ONE>;
-  __shared__ Smem sm;
+  __shared__ X3Smem sm;
   X3P_START
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,10 +187,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
 #pragma unroll
       for (int s = 0; s < KS; ++s) {  // dz1 = dz2 W2: row = input unit n of layer 2, contraction = its output unit
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = a.w2[(32 * s + 8 * g + j) * H + n];
-          if (ONE) v[j] = 0.5f * (a.w3[32 * s + 8 * g + j] * v[j]);  // W2' (the 1/2: the mask operand holds 2.0)
-        }
+        for (int j = 0; j < 8; ++j) v[j] = a.w2[(32 * s + 8 * g + j) * H + n];
         const Frag f = split8(v);
         w2t_h[u][s] = f.h, w2t_m[u][s] = f.m;
       }
@@ -221,21 +200,6 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     split2(v[0], v[1], h0, m0, l0);
     split2(v[2], v[3], h1, m1, l1);
     *reinterpret_cast<u32x2*>(sm.w2l + img_off(n, c4 >> 1) + 8 * (c4 & 1)) = u32x2{l0, l1};
-    if constexpr (ONE) {  // the same layout for W2' = w3[out] W2[out][in] / 2
-      const float s3 = a.w3[n];
-      split2(0.5f * (s3 * v[0]), 0.5f * (s3 * v[1]), h0, m0, l0);
-      split2(0.5f * (s3 * v[2]), 0.5f * (s3 * v[3]), h1, m1, l1);
-      *reinterpret_cast<u32x2*>(sm.w2pl + img_off(n, c4 >> 1) + 8 * (c4 & 1)) = u32x2{l0, l1};
-    }
-  }
-  if constexpr (ONE) {
-    if (tid < 256) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t k = (((tid >> (2 * q)) & 1) ? 0x0000ffffu : 0u) | (((tid >> (2 * q + 1)) & 1) ? 0xffff0000u : 0u);
-        sm.lutk[tid][q] = k, sm.lut2[tid][q] = k & 0x40004000u;
-      }
-    }
   }
   for (int e = tid; e < H * 16; e += THREADS) {  // W1 image: row = hidden unit, pairs of input features
     const int n = e >> 4, kp = e & 15;
@@ -291,11 +255,11 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     return f;
   };
   char* const smb = reinterpret_cast<char*>(&sm);
-  char* const i_h1 = smb + offsetof(Smem, h1);
-  char* const i_z2 = smb + offsetof(Smem, z2);
-  char* const i_z1 = smb + offsetof(Smem, z1);
-  const char* const i_w2l = smb + offsetof(Smem, w2l);
-  const char* const i_w1 = smb + offsetof(Smem, w1);
+  char* const i_h1 = smb + offsetof(X3Smem, h1);
+  char* const i_z2 = smb + offsetof(X3Smem, z2);
+  char* const i_z1 = smb + offsetof(X3Smem, z1);
+  const char* const i_w2l = smb + offsetof(X3Smem, w2l);
+  const char* const i_w1 = smb + offsetof(X3Smem, w1);
 
   // ---- input staging.  Global addresses are a wave-uniform base (SGPRs: the tile's first row) plus a
   // 32-bit lane offset rebuilt at each use: per-lane 64-bit pointers cost six registers here, were
@@ -445,7 +409,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
   // ---- layer 1 of the tile staged in x[xbuf]: h1 = relu(x W1^T + b1) -> image, sign bits -> mask1 ----
   uint32_t mask1 = 0;
   auto layer1 = [&](int xbuf) {
-    const char* const i_x = smb + offsetof(Smem, x) + xbuf * (3 * IMG32);
+    const char* const i_x = smb + offsetof(X3Smem, x) + xbuf * (3 * IMG32);
     Frag w1f[U], xb[TL];
 #pragma unroll
     for (int u = 0; u < U; ++u) w1f[u] = ld_row<4 * IMG32>(i_w1, a_row32 + 1024 * strip(u));
@@ -529,7 +493,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     asm volatile("" : "+v"(a_row), "+v"(a_tr), "+v"(a_row32), "+v"(a_tr32));
     const int64_t m0 = tile * kX3Rows;
     const bool has_next = tile + stride < tiles, has_next2 = tile + 2 * stride < tiles;
-    const char* const i_x = smb + offsetof(Smem, x) + buf * (3 * IMG32);
+    const char* const i_x = smb + offsetof(X3Smem, x) + buf * (3 * IMG32);
     // the input of tile i+1 (in registers since a tile ago) goes to LDS, the loads of tile i+2 start.
     // Training does this in S5: loads and stores share vmcnt and hipcc waits for ALL of it before the
     // loads' destination registers are written, which here would mean the dx stores of S7
@@ -617,7 +581,6 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
             loss += diff * diff;
             g_b3 += d;
           }
-          if (ONE) sm.dd[16 * t + li] = d;  // (every lane group of every wave: the same value)
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             float z[4];
@@ -628,7 +591,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
               z[r] = h2[u][tt][r] > 0.f ? dw : 0.f;
               g_b2[u][r] += z[r];
             }
-            if (!ONE) st4(i_z2, a_out[u] + 4096 * t, z);
+            st4(i_z2, a_out[u] + 4096 * t, z);
           }
         }
       }
@@ -654,44 +617,8 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     {
       Frag za[U], hk[2];
       hk[0] = ld_tr<IMG, 4096>(i_h1, a_tr);
-      if constexpr (ONE) {
-        // this wave's h2 > 0 bits: ballot (tt, r) holds unit 4 g + r of row 16 tt + li at bit 16 g + li (eight named
-        // scalars, not an array: a lane-dependent choice among array elements goes through scratch)
-        const unsigned long long bal00 = __ballot(h2[0][0][0] > 0.f), bal01 = __ballot(h2[0][0][1] > 0.f),
-                                 bal02 = __ballot(h2[0][0][2] > 0.f), bal03 = __ballot(h2[0][0][3] > 0.f),
-                                 bal10 = __ballot(h2[0][1][0] > 0.f), bal11 = __ballot(h2[0][1][1] > 0.f),
-                                 bal12 = __ballot(h2[0][1][2] > 0.f), bal13 = __ballot(h2[0][1][3] > 0.f);
-        {
-          // ... for every wave's dz1 (S6): the bit image [row][unit / 8].  A lane's nibble = its four units of row
-          // 16 tt + li; the four lane groups' nibbles meet by two row swaps (as sum_groups), lanes g == tt store
-          auto row_bits = [&](float v0, float v1, float v2, float v3) {
-            uint32_t v = ((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u)) << (4 * g);
-            auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-            v = p[0] | p[1];
-            auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-            return q[0] | q[1];
-          };
-          const uint32_t m0b = row_bits(h2[0][0][0], h2[0][0][1], h2[0][0][2], h2[0][0][3]);
-          const uint32_t m1b = row_bits(h2[0][1][0], h2[0][1][1], h2[0][1][2], h2[0][1][3]);
-          if (g < 2) *reinterpret_cast<uint16_t*>(&sm.maskimg[16 * g + li][2 * w]) = (uint16_t)(g ? m1b : m0b);
-        }
-        // A operand: lane (li, g) = unit li of the wave, contraction position j <-> row 16 (j >> 2) + 4 g + (j & 3)
-        // (tr_frag's map): the split of d at those rows, each kept or cleared by the unit's bit of that row
-        const f32x4 dlo = *reinterpret_cast<const f32x4*>(&sm.dd[4 * g]);  // (this wave's own stores, executed in order)
-        const f32x4 dhi = *reinterpret_cast<const f32x4*>(&sm.dd[16 + 4 * g]);
-        const float dv[8] = {dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
-        za[0] = split8(dv);
-        const int sh = 16 * (li >> 2) + 4 * g;
-        const bool r1 = (li & 1) != 0, r2 = (li & 2) != 0;  // unit li of the wave = 4 (li >> 2) + (li & 3)
-        const unsigned long long b0a = r1 ? bal01 : bal00, b0b = r1 ? bal03 : bal02, b0 = r2 ? b0b : b0a;
-        const unsigned long long b1a = r1 ? bal11 : bal10, b1b = r1 ? bal13 : bal12, b1 = r2 ? b1b : b1a;
-        const uint32_t byte = ((uint32_t)(b0 >> sh) & 0xfu) | (((uint32_t)(b1 >> sh) & 0xfu) << 4);
-        const u32x4 keep = *reinterpret_cast<const u32x4*>(&sm.lutk[byte][0]);
-        za[0].h &= keep, za[0].m &= keep, za[0].l &= keep;
-      } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) za[u] = own_tr(i_z2, a_tr ^ (32 * strip(u)));
-      }
+      for (int u = 0; u < U; ++u) za[u] = own_tr(i_z2, a_tr ^ (32 * strip(u)));
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) hk[(kt + 1) & 1] = ld_tr<IMG, 4096>(i_h1, a_tr ^ (32 * (kt + 1)));
@@ -703,90 +630,48 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
     }
     X3P_SYNC(3)  // B3
     // ---- S6: dz1[:, units] = (dz2 W2) (.) (h1 > 0) -------------------------------------------------
-    if constexpr (ONE) {
-      // dz1 = d (.) (M W2') with M[r][u] = 2 [h2[r][u] > 0] in ONE bf16 term: three MFMAs per step (the terms of W2'
-      // against it, smallest first).  B operand: lane (li, g) = row 16 tt + li, units 32 s + 8 g + j: the pattern of
-      // byte 4 s + g of the row's 16 bytes of the bit image.  W2''s third term: the transposed read of its image.
-      const int a0 = 2048 * g + 256 * q4 + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (sw(q4) & 1)) + ((32 * w) ^ (16 * (sw(q4) & 14)));
-      const char* const i_w2pl = smb + offsetof(Smem, w2pl);
-      const u32x4 mrow0 = *reinterpret_cast<const u32x4*>(&sm.maskimg[li][0]);
-      const u32x4 mrow1 = *reinterpret_cast<const u32x4*>(&sm.maskimg[16 + li][0]);
-      u32x4 wl[KS];
+    {
+      Frag zb[2];
+      // W2^T's third term: lane (li, g) = input unit unit0 + li, output units 32 s + 8 g + j: transposed
+      // read of rows 32 s + 8 g + q (+ 4) of the image; their swizzles differ by sw(q + 4) = sw(q) ^ 9
+      u32x4 wl[U][KS];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const u32x2 lo = lds_read_tr(i_w2pl + a0 + 8192 * s), hi = lds_read_tr(i_w2pl + (a0 ^ 144) + 8192 * s + 1024);
-        wl[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-      }
-      u32x4 mb[2][KS];
+      for (int u = 0; u < U; ++u) {
+        const int a0 = 2048 * g + 256 * q4 + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (sw(q4) & 1)) +
+                       ((32 * strip(u)) ^ (16 * (sw(q4) & 14)));
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        mb[0][s] = *reinterpret_cast<const u32x4*>(&sm.lut2[(mrow0[s] >> (8 * g)) & 0xffu][0]);
-        mb[1][s] = *reinterpret_cast<const u32x4*>(&sm.lut2[(mrow1[s] >> (8 * g)) & 0xffu][0]);
-      }
-      const float d_own[2] = {sm.dd[li], sm.dd[16 + li]};  // (of this tile: rewritten in S5 of the next)
-      X3_PIN
-      f32x4 c[2] = {zero4, zero4};
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          c[tt] = mfma16(wl[s], mb[tt][s], c[tt]);
-          c[tt] = mfma16(w2t_m[0][s], mb[tt][s], c[tt]);
-          c[tt] = mfma16(w2t_h[0][s], mb[tt][s], c[tt]);
+        for (int s = 0; s < KS; ++s) {
+          const u32x2 lo = lds_read_tr(i_w2l + a0 + 8192 * s), hi = lds_read_tr(i_w2l + (a0 ^ 144) + 8192 * s + 1024);
+          wl[u][s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
-      X3_PIN
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        float z[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          z[r] = ((mask1 >> (4 * tt + r)) & 1u) ? c[tt][r] * d_own[tt] : 0.f;
-          g_b1[0][r] += z[r];
-        }
-        st4(i_z1, a_out[0] + 4096 * tt, z);
       }
-    } else {
-        Frag zb[2];
-        // W2^T's third term: lane (li, g) = input unit unit0 + li, output units 32 s + 8 g + j: transposed
-        // read of rows 32 s + 8 g + q (+ 4) of the image; their swizzles differ by sw(q + 4) = sw(q) ^ 9
-        u32x4 wl[U][KS];
+      zb[0] = ld_row<IMG>(i_z2, a_row + 4096 * th);
+#pragma unroll
+      for (int tt = 0; tt < TL; ++tt) {
+        f32x4 c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = zero4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int i = KS * tt + s;
+          if (i + 1 < KS * TL)
+            zb[(i + 1) & 1] = ld_row<IMG>(i_z2, (a_row ^ (64 * ((s + 1) % KS))) + 4096 * (th + (i + 1) / KS));
+          X3_PIN
+#pragma unroll
+          for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2t_h[u][s], w2t_m[u][s], wl[u][s]}, zb[i & 1], c[u]);
+          X3_PIN
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int a0 = 2048 * g + 256 * q4 + 8 * (p4 & 1) + 16 * ((p4 >> 1) ^ (sw(q4) & 1)) +
-                         ((32 * strip(u)) ^ (16 * (sw(q4) & 14)));
+          float z[4];
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const u32x2 lo = lds_read_tr(i_w2l + a0 + 8192 * s), hi = lds_read_tr(i_w2l + (a0 ^ 144) + 8192 * s + 1024);
-            wl[u][s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          for (int r = 0; r < 4; ++r) {
+            z[r] = ((mask1 >> (8 * u + 4 * tt + r)) & 1u) ? c[u][r] : 0.f;
+            g_b1[u][r] += z[r];
           }
+          st4(i_z1, a_out[u] + 4096 * (th + tt), z);
         }
-        zb[0] = ld_row<IMG>(i_z2, a_row + 4096 * th);
-#pragma unroll
-        for (int tt = 0; tt < TL; ++tt) {
-          f32x4 c[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) c[u] = zero4;
-#pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const int i = KS * tt + s;
-            if (i + 1 < KS * TL)
-              zb[(i + 1) & 1] = ld_row<IMG>(i_z2, (a_row ^ (64 * ((s + 1) % KS))) + 4096 * (th + (i + 1) / KS));
-            X3_PIN
-#pragma unroll
-            for (int u = 0; u < U; ++u) c[u] = mma6(Frag{w2t_h[u][s], w2t_m[u][s], wl[u][s]}, zb[i & 1], c[u]);
-            X3_PIN
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            float z[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              z[r] = ((mask1 >> (8 * u + 4 * tt + r)) & 1u) ? c[u][r] : 0.f;
-              g_b1[u][r] += z[r];
-            }
-            st4(i_z1, a_out[u] + 4096 * (th + tt), z);
-          }
-        }
+      }
     }
     // ---- S6b: dW1[units][:] += dz1^T x (this wave's own dz1 columns, as dW2 above) -------------------
     {
@@ -947,8 +832,7 @@ __global__ __launch_bounds__(kX3Threads / U) void tiny_mlp_x3_kernel(const Fused
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)  // (ONE: the unit's factor w3, taken out of the sum over the batch)
-        p_w2[(n + r) * H + 16 * kt + li] = ONE ? g_w2[u][kt][r] * sm.w3[n + r] : g_w2[u][kt][r];
+      for (int r = 0; r < 4; ++r) p_w2[(n + r) * H + 16 * kt + li] = g_w2[u][kt][r];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -1147,8 +1031,6 @@ int launch_tiny_mlp_x3(const FusedArgs& a, int hidden, bool train, int blocks, h
     hipLaunchKernelGGL((tiny_mlp_x3_kernel<false, 1, 64>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (train && wide)
     hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 2, 128>), dim3(blocks), dim3(kX3Threads / 2), 0, st, a, none);
-  else if (train && options().mlp_x3 == 3)  // (3: dz2 as an LDS image and six products for dz1, as until round 3: A/B runs)
-    hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 128, 0, false>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (train)
     hipLaunchKernelGGL((tiny_mlp_x3_kernel<true, 1, 128>), dim3(blocks), dim3(kX3Threads), 0, st, a, none);
   else if (wide)
