@@ -152,13 +152,19 @@ __device__ __forceinline__ void issue_chunk(const char* __restrict__ wsplit, int
   }
 }
 
-// One 16-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x CT tile.  a_k: the
-// lane's image row at the chunk's first k, + 4 lh; boff[t]: byte offset of the lane's slot of its
-// column 32 t in a term plane.
+// One 16-deep chunk of acc[t] += img[rows][k] * W[cols_t][k] for the wave's 32 x CT tile.  boff[t]: byte offset of
+// the lane's slot of its column 32 t in a term plane.  The image operand is software-pipelined over the chunks of a
+// layer (round 4): `fa` holds THIS chunk's fragment, already split (the image is complete when a layer starts, only
+// the weights arrive chunk by chunk); the f32 words of the NEXT chunk's fragment (`a_next`: the lane's image row at
+// that chunk's first k, + 4 lh; null for a layer's last chunk) are requested together with this chunk's weight
+// fragments and split while this chunk's MFMAs execute -- read and split in front of its own MFMAs, as until round
+// 3, the 44 vector instructions and an LDS round trip stood between every chunk barrier and the first MFMA behind
+// it: config 3 13.31 -> 12.64 ms on one box (forward 5.55 -> 5.14, backward 7.74 -> 7.45), bit-identical results.
+// (The weight fragments a chunk ahead as well -- a three-deep DMA ring, the MFMAs of a chunk finding both operands
+// in registers -- measured 13.10 against 13.32 ms: 24 more registers and a third 24 KiB buffer for less.)
 template <int NT, int H>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], const float* __restrict__ a_k,
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], x3::Frag& fa, const float* __restrict__ a_next,
                                           const char* __restrict__ wb, const int (&boff)[NT]) {
-  const float4 a_lo = *reinterpret_cast<const float4*>(a_k), a_hi = *reinterpret_cast<const float4*>(a_k + 8);
   x3::Frag fb[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -166,9 +172,15 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], const float* __rest
     fb[t].m = *reinterpret_cast<const x3::u32x4*>(wb + H * 32 + boff[t]);
     fb[t].l = *reinterpret_cast<const x3::u32x4*>(wb + 2 * H * 32 + boff[t]);
   }
-  const x3::Frag fa = split_octets(a_lo, a_hi);
+  float4 n_lo = {0.f, 0.f, 0.f, 0.f}, n_hi = n_lo;
+  if (a_next) n_lo = *reinterpret_cast<const float4*>(a_next), n_hi = *reinterpret_cast<const float4*>(a_next + 8);
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = mma6_32(fa, fb[t], acc[t]);
+  if (a_next) fa = split_octets(n_lo, n_hi);
+}
+// the first fragment of a layer (behind the barrier that completes the image)
+__device__ __forceinline__ x3::Frag first_fragment(const float* __restrict__ a_k) {
+  return split_octets(*reinterpret_cast<const float4*>(a_k), *reinterpret_cast<const float4*>(a_k + 8));
 }
 
 // Phase timing for tools/siren_phases.py (a tools-only build with -DSIREN_PROFILE; the shipped
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      x3::Frag fa;
 #pragma unroll
       for (int kc = 0; kc < S::chunks; ++kc, ++s) {
         // Chunk s has landed (this wave's own pieces; vmcnt counts loads, stores and LDS-DMA
@@ -329,7 +342,8 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
         __builtin_amdgcn_sched_barrier(0);
         drip(kc * S::drip, (kc + 1) * S::drip, full_tile);
         SP_MARK(3)  // DMA issue + dripped stores
-        mma_chunk<NT, H>(acc, a_row + kc * kKc, sm.wbuf[s & 1], boff);
+        if (kc == 0) fa = first_fragment(a_row);  // (the barrier above completed the image)
+        mma_chunk<NT, H>(acc, fa, kc + 1 < S::chunks ? a_row + (kc + 1) * kKc : nullptr, sm.wbuf[s & 1], boff);
         SP_MARK(4)  // fragment reads + MFMAs
       }
       pend_l = -1;  // fully dripped
@@ -623,6 +637,7 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       float dv[NT][16];
+      x3::Frag fa;
 #pragma unroll
       for (int kc = 0; kc < S::chunks; ++kc, ++s) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -637,7 +652,8 @@ __global__ __launch_bounds__(kThreads) void siren_backward_kernel(const BwdArgs 
         __builtin_amdgcn_sched_barrier(0);
         drip(kc * S::drip, (kc + 1) * S::drip, full_tile);
         if (kc == 0) load_deriv(a.deriv[l - 1], m0, full_tile, dv);  // lands beside the MFMAs
-        mma_chunk<NT, H>(acc, a_row + kc * kKc, sm.wbuf[s & 1], boff);
+        if (kc == 0) fa = first_fragment(a_row);  // (the barrier above completed the image)
+        mma_chunk<NT, H>(acc, fa, kc + 1 < S::chunks ? a_row + (kc + 1) * kKc : nullptr, sm.wbuf[s & 1], boff);
       }
       pend_l = -1;
 #pragma unroll
