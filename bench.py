@@ -292,13 +292,6 @@ def main():
                          "(measured: the lookup gets its 8 us back, the step does not -- the work only moves)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="produce every batch on the main stream at the start of its step")
-    ap.add_argument("--batch-order", choices=("morton", "shuffled"), default="shuffled",
-                    help="order of a batch's rows (the SET is the epoch's shuffle either way; the loss is a mean over "
-                         "it): 'shuffled' leaves them as the permutation yields them; 'morton' re-orders them on the "
-                         "device along a Morton curve, transposed inside blocks of 16384 rows (mri_order_batch) -- every "
-                         "kernel of the step then runs faster (lookup -8 us, scatter + accumulate -5 us) and the step "
-                         "does not, 0.535 against 0.512 ms: 32 us of ordering per step have nowhere to hide "
-                         "(DESIGN.md 8)")
     ap.add_argument("--cold-start", action="store_true",
                     help="time the first leg on a device that has just left idle (the order until round 3: timed legs, "
                          "then the quality leg); by default the quality leg's training steps run first, so that every "
@@ -309,9 +302,9 @@ def main():
                          "0.56 ms per step with n = 1, round 3).  0 (default) = max(6, steps // 5): five sampled "
                          "steps in a long run, three in the driver's 20-step form (steps 4, 10, 16), so that "
                          "phases_ms / rooflines.*.ms_per_launch are means of >= 3 launches")
-    ap.add_argument("--launch", default="native", choices=["native", "graph", "eager"],
+    ap.add_argument("--launch", default="native", choices=["native", "eager"],
                     help="how a step is queued (trainer.SteadyLoop): native = one mri_fused_step call per step; "
-                         "graph = hipGraph replay; eager = op by op from Python")
+                         "eager = op by op from Python")
     ap.add_argument("--fixed-batch", action="store_true",
                     help="diagnostic: train on the first batch over and over (no batch is produced inside the "
                          "timed steps): what the on-device batch producer costs a step; never a measured line")
@@ -420,8 +413,7 @@ def main():
     # shuffled batches, epoch after epoch; batch k+1 is produced while step k runs (queued on
     # the step's side stream, or after Adam when the step has none): its kernels still execute
     # inside the timed region
-    pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group,
-                                     order=args.batch_order)
+    pipe = datamodules.BatchPipeline(loader, group=1 if args.no_prefetch else args.batch_group)
 
     # One GPU, fused hash-grid + tiny-MLP step: queued by ONE library call per step (trainer.SteadyLoop ->
     # mri_fused_step: the same launches on the same data, bit-identical parameters) -- queued op by op from
@@ -431,7 +423,7 @@ def main():
 
     def capture_graphs():
         graphed[0] = None
-        if args.launch == "eager" or args.fixed_batch or args.no_prefetch or (world != 1 and args.launch == "graph"):
+        if args.launch == "eager" or args.fixed_batch or args.no_prefetch:
             return
         if trainer.SteadyLoop.unsupported(step, pipe) is None:
             try:
@@ -446,8 +438,6 @@ def main():
         every = max(1, args.phase_every)
         step.phase_events = events if sampling[0] and (k - leg_start[0]) % every == min(3, every - 1) else None
         if graphed[0] is not None:
-            if step.phase_events is not None and args.launch != "native":
-                return graphed[0].eager_step()
             return graphed[0].step_once(sample=step.phase_events is not None)
         coords, target = pipe.current()
         if args.fixed_batch:
@@ -599,8 +589,7 @@ def main():
             "phases_sampled_every": max(1, args.phase_every),
             "phases_samples": best.get("phase_samples"),  # launches behind each phases_ms / ms_per_launch mean
             "host_queue_ms_per_step": round(best["host_ms"], 4),
-            "launch": {"native": "one mri_fused_step call per step (phase events recorded inside the call)",
-                       "graph": "hipGraph replay per step (sample steps eager)"}[args.launch]
+            "launch": "one mri_fused_step call per step (phase events recorded inside the call)"
             if graphed[0] is not None else (launch_note[0] or "eager (queued op by op from Python)"),
             "final_loss": best["loss"],
         }
@@ -624,7 +613,7 @@ def main():
         if packed is not None:
             result["packed_records"] = packed
         result["device_warmup"] = device_warmup
-        result["batch_order"] = pipe.order
+        result["batch_order"] = "shuffled (the order the epoch's permutation yields; the spatially ordered form of round 3 was removed)"
         if psnr is not None:
             result["psnr"] = psnr
         if cpu is not None:

@@ -80,21 +80,6 @@ const char* mri_last_error(void);
  * records against float64, tests/test_gpu_round3.py). */
 int mri_set_option(const char* name, int32_t value);
 
-/* Step-dependent scalars in DEVICE memory, for callers that replay a captured step (hipGraph): a captured
- * launch bakes its by-value arguments in, so what changes from step to step -- Adam's bias-correction
- * prefactors (reference models.py:68-70, torch.optim.Adam: computed on the host per step) and the position
- * of the batch in the epoch's shuffle (datamodules.py:198-205) -- is read from this block by the `_dev`
- * entry points.  The caller fills a HOST copy with mri_step_params_fill (exactly the values mri_adam_step /
- * mri_sample_indices derive from the same arguments: results are bit-identical) and copies it to the device
- * (stream-ordered, e.g. hipMemcpyAsync from pinned memory) before each replay. */
-typedef struct mri_step_params {
-  float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, reserved;
-  uint64_t sample_key;   /* scrambled seed of the epoch's permutation */
-  int64_t sample_first;  /* position of the batch's first element in that permutation */
-} mri_step_params;
-int mri_step_params_fill(mri_step_params* host_out, double lr, double beta1, double beta2, double eps,
-                         int32_t step, float grad_scale, uint64_t sample_seed, int64_t sample_first);
-
 /* ---- hash-grid encoding --------------------------------------------------------------
  * Replaces, per level, the op chain of _HashGrid.forward / _HashGridV2.forward
  * (reference encoding.py:108-128, 232-270) incl. fast_hash (encoding.py:69-78), and the
@@ -422,9 +407,6 @@ int mri_mse_loss(const float* pred, const float* target, int64_t count, float gr
 int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t count, double lr, double beta1, double beta2, double eps,
                   int32_t step, float grad_scale, void* stream);
-/* The same launch with its prefactors read from a device-resident mri_step_params (hipGraph replays). */
-int mri_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                      int64_t count, const mri_step_params* dev_params, void* stream);
 
 /* ---- one training step, queued by one call ----------------------------------------------------
  * The per-batch body of the reference's training loop for its HashMLP path with the tiny-MLP decoder
@@ -482,8 +464,6 @@ typedef struct mri_fused_step_args {
                                                     parallel: the world size, with n_params = 0 -- the caller
                                                     reduces `grad` over the ranks and steps (mri_adam_step) */
   float reserved2;
-  void* order_ws;                                /* the next batch in spatial order (mri_order_gather_batch in place of */
-  int64_t order_ws_bytes;                        /* mri_gather_batch), or NULL: shuffle order */
 } mri_fused_step_args;
 int mri_fused_step(const mri_fused_step_args* args);
 int64_t mri_fused_step_args_bytes(void); /* sizeof(mri_fused_step_args): lets a binding check its layout */
@@ -499,30 +479,9 @@ int64_t mri_fused_step_args_bytes(void); /* sizeof(mri_fused_step_args): lets a 
  *   shape / axis_offset are HOST arrays of length D. */
 int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int64_t hi, int64_t n,
                        int64_t* idx_out, void* stream);
-/* The same launch with (key of the seed, first) read from a device-resident mri_step_params. */
-int mri_sample_indices_dev(const mri_step_params* dev_params, int64_t lo, int64_t hi, int64_t n,
-                           int64_t* idx_out, void* stream);
 int mri_gather_batch(const int64_t* idx, int64_t n, int32_t dim, const int64_t* shape,
                      const float* axes, const int64_t* axis_offset, const float* volume,
                      float* coords_out, float* target_out /* may be NULL */, void* stream);
-/* mri_order_batch: reorders the n flat voxel indices of ONE batch in place -- the set is the shuffle's, the
- *   order of a batch's rows is free (reference models.py:61-66: F.mse_loss is a mean over the batch; the table
- *   gradient a sum) -- by the 12 highest bits of a Morton key over the `dim` axes (8 bits per axis, position /
- *   extent; rows of a bucket keep their shuffle order: one stable counting pass), then transposed inside blocks of
- *   16384 rows: a wave's 64 rows are 64 different neighbourhoods (no two lanes add
- *   into the same table slot, as in a shuffled batch), consecutive waves are Morton neighbours (the lookup finds
- *   their cache lines again: BASELINE config 4 0.099 -> 0.090 ms, the table gradient 0.222 -> 0.214 ms on the
- *   same batch).  Deterministic (ranks from chunk, wave and lane order: the same indices give the same order every run).
- *   `shape` is a HOST array of length dim; workspace: mri_order_batch_workspace_bytes(n, dim), 256-byte aligned. */
-int64_t mri_order_batch_workspace_bytes(int64_t n, int32_t dim);
-int mri_order_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, void* workspace,
-                    int64_t workspace_bytes, void* stream);
-/* mri_order_batch followed by mri_gather_batch on the ordered indices, with the gather done by the ordering's last
- *   launch (same indices, coordinates and targets). */
-int mri_order_gather_batch(int64_t* idx, int64_t n, int32_t dim, const int64_t* shape, const float* axes,
-                           const int64_t* axis_offset, const float* volume, float* coords_out,
-                           float* target_out /* may be NULL */, void* workspace, int64_t workspace_bytes,
-                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,14 +33,6 @@ class GridDesc(C.Structure):
     ]
 
 
-class StepParams(C.Structure):
-    """struct mri_step_params (filled on the host, copied to the device before a graph replay)."""
-    _fields_ = [("one_minus_b1", C.c_float), ("b2", C.c_float), ("one_minus_b2", C.c_float),
-                ("neg_step_size", C.c_float), ("bc2_sqrt", C.c_float), ("eps", C.c_float),
-                ("grad_scale", C.c_float), ("reserved", C.c_float),
-                ("sample_key", C.c_uint64), ("sample_first", C.c_int64)]
-
-
 class FusedStepArgs(C.Structure):
     """struct mri_fused_step_args (host memory; every pointer a device pointer unless noted)."""
     _fields_ = (
@@ -60,8 +52,7 @@ class FusedStepArgs(C.Structure):
            ("shape", C.c_int64 * MAX_DIM), ("axis_offset", C.c_int64 * MAX_DIM), ("axes", C.c_void_p),
            ("volume", C.c_void_p)]
         + [(k, C.c_void_p) for k in ("stream", "stream_side", "ev_fork", "ev_join")]
-        + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float),
-           ("order_ws", C.c_void_p), ("order_ws_bytes", C.c_int64)])
+        + [("ev_phase", C.c_void_p * 5), ("grad_divisor", C.c_float), ("reserved2", C.c_float)])
 
 
 _P = C.c_void_p
@@ -118,18 +109,12 @@ SIGNATURES = {
                                _I64, _P],
     "mri_adam_step": [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _F, _P],
     "mri_sample_indices": [C.c_uint64, _I64, _I64, _I64, _I64, _P, _P],
-    "mri_step_params_fill": [_P, _D, _D, _D, _D, _I32, _F, C.c_uint64, _I64],
     "mri_fused_step": [_P],
-    "mri_adam_step_dev": [_P, _P, _P, _P, _I64, _P, _P],
-    "mri_sample_indices_dev": [_P, _I64, _I64, _I64, _P, _P],
     "mri_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P],
-    "mri_order_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, _I64, _P],
-    "mri_order_gather_batch": [_P, _I64, _I32, C.POINTER(_I64), _P, C.POINTER(_I64), _P, _P, _P, _P, _I64, _P],
 }
 STRING_GETTERS = ["mri_version", "mri_last_error"]
 INT64_GETTERS = {"mri_hashgrid_backward_workspace_bytes": [C.POINTER(GridDesc), _I64],
                  "mri_fused_step_args_bytes": [],
-                 "mri_order_batch_workspace_bytes": [_I64, _I32],
                  "mri_tiny_mlp_workspace_bytes": [_I32, _I32, _I64],
                  "mri_siren_backward_workspace_bytes": [_I64, _I32, _I32],
                  "mri_siren_forward_workspace_bytes": [_I32, _I32],

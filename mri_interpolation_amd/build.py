@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libmri_inr.so")
 SOURCES = ["hashgrid.hip", "hashgrid_bwd.hip", "linear.hip", "linear_small.hip", "mlp_fused.hip", "mlp_x3.hip", "train_ops.hip",
-           "frequency.hip", "siren_chain.hip", "fused_step.hip", "batch_order.hip"]
+           "frequency.hip", "siren_chain.hip", "fused_step.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          # the reference multiplies and adds separately (encoding.py:111-128, torch Adam);
          # keep those roundings instead of contracting to fma

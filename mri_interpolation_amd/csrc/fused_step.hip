@@ -4,7 +4,7 @@
 // ctypes call per op through torch's stream and event objects -- that costs 0.2 ... 0.55 ms of host time
 // per step depending on the box (tools/host_profile.py: 57 % of it interpreter and wrapper overhead), against
 // 0.52 ms of GPU time: on a slow host the loop is HOST-bound.  hipGraph replays do not help on this
-// runtime (a replay of the same step costs the host 0.46 ms: trainer.GraphedLoop).  This entry
+// runtime (a replay of the same step cost the host 0.46 ms: EXPERIMENTS.md, round 3).  This entry
 // point composes the library's own entry points in C: the host cost of a step is one call plus the HIP
 // launches themselves.
 //
@@ -71,13 +71,9 @@ extern "C" int mri_fused_step(const mri_fused_step_args* a) {
   if (a->next_idx) {  // next batch: sample + gather, zero its absmax buffer, count its records
     if ((rc = mri_sample_indices(a->seed, a->first, a->lo, a->hi, a->next_n, a->next_idx, side))) return rc;
     TRACE(1)
-    if (a->order_ws)  // its rows in spatial order (the set is the shuffle's), gathered by the ordering's last launch
-      rc = mri_order_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
-                                  a->next_coords, a->next_target, a->order_ws, a->order_ws_bytes, side);
-    else
-      rc = mri_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
-                            a->next_coords, a->next_target, side);
-    if (rc) return rc;
+    if ((rc = mri_gather_batch(a->next_idx, a->next_n, a->dim, a->shape, a->axes, a->axis_offset, a->volume,
+                               a->next_coords, a->next_target, side)))
+      return rc;
     TRACE(2)
     if (a->next_absmax && hipMemsetAsync(a->next_absmax, 0, 32 * sizeof(float), side) != hipSuccess)
       return fail(MRI_ERR_LAUNCH, "fused step: memset");

@@ -54,8 +54,6 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__
 //   m = m + (g - m) * (1 - b1)            (Tensor.lerp_)
 //   v = v * b2 + (1 - b2) * g * g         (mul_ then addcmul_)
 //   p = p + (-step_size * m) / (sqrt(v) / sqrt(bc2) + eps)    (addcdiv_)
-// `dev` (hipGraph replays: the step-dependent prefactors cannot be baked into a captured launch): when
-// non-null, the scalars are read from that device-resident block instead of the by-value arguments.
 // FIN (mri_fused_step): where a segment of `fin` covers an element, its gradient is the table gradient's int64 sum,
 // converted here exactly as bin_finalize_kernel would have (hashgrid_common.h) -- that launch then never happens.
 template <bool FIN>
@@ -64,13 +62,7 @@ __device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __
                                           int64_t count, float one_minus_b1, float b2,
                                           float one_minus_b2, float neg_step_size,
                                           float bc2_sqrt, float eps, float grad_scale,
-                                          int head, const mri_step_params* __restrict__ dev,
-                                          const FinTab& fin) {
-  if (dev) {  // wave-uniform scalar loads
-    one_minus_b1 = dev->one_minus_b1, b2 = dev->b2, one_minus_b2 = dev->one_minus_b2;
-    neg_step_size = dev->neg_step_size, bc2_sqrt = dev->bc2_sqrt, eps = dev->eps;
-    grad_scale = dev->grad_scale;
-  }
+                                          int head, const FinTab& fin) {
   // p/g/m/v point at the first 16-byte aligned element of the range; the `head` (< 4) elements in
   // front of it (a range that starts inside a float4, e.g. a level group of the hash table) are
   // taken one each by the first threads of block 0
@@ -145,9 +137,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    int64_t count, float one_minus_b1, float b2,
                                                    float one_minus_b2, float neg_step_size,
                                                    float bc2_sqrt, float eps, float grad_scale,
-                                                   int head, const mri_step_params* __restrict__ dev) {
+                                                   int head) {
   adam_body<false>(p, g, m, v, count, one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, head,
-                   dev, FinTab{});
+                   FinTab{});
 }
 __global__ __launch_bounds__(256) void adam_fin_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
@@ -156,7 +148,7 @@ __global__ __launch_bounds__(256) void adam_fin_kernel(float* __restrict__ p, co
                                                        float bc2_sqrt, float eps, float grad_scale,
                                                        const FinTab fin) {
   adam_body<true>(p, g, m, v, count, one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps, grad_scale, 0,
-                  nullptr, fin);
+                  fin);
 }
 
 // ---------------------------------------------------------------------------------- sampler
@@ -188,11 +180,9 @@ __device__ __forceinline__ uint64_t feistel(uint64_t v, int half_bits, uint64_t 
 
 __global__ __launch_bounds__(256) void sample_kernel(uint64_t key, int64_t first, int64_t lo,
                                                      int64_t range, int half_bits, int64_t n,
-                                                     int64_t* __restrict__ out,
-                                                     const mri_step_params* __restrict__ dev) {
+                                                     int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (dev) key = dev->sample_key, first = dev->sample_first;  // hipGraph replays, see adam_kernel
   uint64_t v = (uint64_t)((first + i) % range);
   do {
     v = feistel(v, half_bits, key);
@@ -313,8 +303,7 @@ extern "C" int mri_adam_step(float* param, const float* grad, float* exp_avg, fl
   const int64_t blocks = std::max<int64_t>(1, ceil_div(ceil_div(count, 4), 256));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      param, grad, exp_avg, exp_avg_sq, count, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), neg_step_size, bc2_sqrt, (float)eps, grad_scale, head,
-                     (const mri_step_params*)nullptr);
+                     (float)(1.0 - beta2), neg_step_size, bc2_sqrt, (float)eps, grad_scale, head);
   return check_launch("adam_kernel");
 }
 
@@ -328,40 +317,6 @@ uint64_t sample_key(uint64_t seed) {  // scramble the user seed so that nearby s
 }
 }  // namespace
 
-extern "C" int mri_step_params_fill(mri_step_params* host_out, double lr, double beta1, double beta2,
-                                    double eps, int32_t step, float grad_scale, uint64_t sample_seed,
-                                    int64_t sample_first) {
-  MRI_REQUIRE(host_out != nullptr && step >= 1 && sample_first >= 0, "bad arguments");
-  // exactly what mri_adam_step and mri_sample_indices derive from the same arguments
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2 = 1.0 - pow(beta2, (double)step);
-  host_out->one_minus_b1 = (float)(1.0 - beta1), host_out->b2 = (float)beta2;
-  host_out->one_minus_b2 = (float)(1.0 - beta2), host_out->neg_step_size = (float)(-(lr / bc1));
-  host_out->bc2_sqrt = (float)sqrt(bc2), host_out->eps = (float)eps;
-  host_out->grad_scale = grad_scale, host_out->reserved = 0.f;
-  host_out->sample_key = sample_key(sample_seed), host_out->sample_first = sample_first;
-  return MRI_OK;
-}
-
-extern "C" int mri_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                 int64_t count, const mri_step_params* dev_params, void* stream) {
-  MRI_REQUIRE(count >= 0, "bad count");
-  if (count == 0) return MRI_OK;
-  MRI_REQUIRE(param && grad && exp_avg && exp_avg_sq && dev_params, "NULL device pointer");
-  const uintptr_t mis = reinterpret_cast<uintptr_t>(param) & 15;
-  MRI_REQUIRE((mis & 3) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == mis &&
-                  (reinterpret_cast<uintptr_t>(exp_avg) & 15) == mis &&
-                  (reinterpret_cast<uintptr_t>(exp_avg_sq) & 15) == mis,
-              "Adam buffers must share one 4-byte aligned offset within a 16-byte line");
-  const int head = (int)std::min<int64_t>(count, mis ? (int64_t)(16 - mis) / 4 : 0);
-  param += head, grad += head, exp_avg += head, exp_avg_sq += head, count -= head;
-  const int64_t blocks = std::max<int64_t>(1, ceil_div(ceil_div(count, 4), 256));
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     param, grad, exp_avg, exp_avg_sq, count, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 1.f, head,
-                     dev_params);
-  return check_launch("adam_kernel");
-}
-
 extern "C" int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int64_t hi,
                                   int64_t n, int64_t* idx_out, void* stream) {
   MRI_REQUIRE(hi > lo && first >= 0 && n >= 0, "bad range [%lld, %lld)", (long long)lo,
@@ -374,23 +329,7 @@ extern "C" int mri_sample_indices(uint64_t seed, int64_t first, int64_t lo, int6
   if (bits & 1) ++bits;
   MRI_REQUIRE(bits <= 62, "range too large");
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, sample_key(seed), first, lo, range, bits / 2, n, idx_out,
-                     (const mri_step_params*)nullptr);
-  return check_launch("sample_kernel");
-}
-
-extern "C" int mri_sample_indices_dev(const mri_step_params* dev_params, int64_t lo, int64_t hi,
-                                      int64_t n, int64_t* idx_out, void* stream) {
-  MRI_REQUIRE(hi > lo && n >= 0, "bad range [%lld, %lld)", (long long)lo, (long long)hi);
-  if (n == 0) return MRI_OK;
-  MRI_REQUIRE(idx_out && dev_params, "NULL device pointer");
-  const int64_t range = hi - lo;
-  int bits = 2;
-  while ((1ll << bits) < range) ++bits;
-  if (bits & 1) ++bits;
-  MRI_REQUIRE(bits <= 62, "range too large");
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, 0ull, (int64_t)0, lo, range, bits / 2, n, idx_out, dev_params);
+                     (hipStream_t)stream, sample_key(seed), first, lo, range, bits / 2, n, idx_out);
   return check_launch("sample_kernel");
 }
 

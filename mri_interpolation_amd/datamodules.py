@@ -229,20 +229,10 @@ class BatchPipeline:
     for the main stream at that step's start (group G-1, the buffer's previous user, is then done), and
     every later step is ordered behind that stream (FusedStep: the batch event of the previous step)."""
 
-    def __init__(self, loader: DeviceLoader, group: int = 1, order: str = "shuffled"):
-        """`order`: "shuffled" -- a batch's rows in the order the epoch's permutation yields them -- or "morton":
-        the same rows re-ordered on the device (ops.order_batch: a Morton curve, transposed inside blocks of 16384
-        rows), the order the lookup and table-gradient kernels run fastest on.  WHICH voxels a batch holds is the
-        shuffle's business either way; the loss is a mean over them, the gradients sums."""
-        if order not in ("shuffled", "morton"):
-            raise ValueError(f"BatchPipeline: order {order!r} not in ('shuffled', 'morton')")
+    def __init__(self, loader: DeviceLoader, group: int = 1):
         self.loader = loader
         self.group = max(1, int(group))
-        self.order = order if loader.shuffle else "shuffled"
-        if self.order == "morton" and self.group != 1:
-            raise ValueError("BatchPipeline: order='morton' produces batch by batch (group = 1)")
         dev, bs = loader.ds.device, loader.batch_size
-        self._order_ws = ops.order_batch_workspace(bs, loader.ds.dim_in, dev) if self.order == "morton" else None
         rows = bs * self.group
         self.slots = [(torch.empty(rows, dtype=torch.int64, device=dev),
                        torch.empty(rows, loader.ds.dim_in, device=dev),
@@ -273,12 +263,7 @@ class BatchPipeline:
         total = sum(self.loader.span(b0 + r)[1] for r in range(count))  # only an epoch's last batch is short
         idx, coords, target = self.slots[g % 2]
         self.loader.indices(first, total, self.epoch0 + e, out=idx[:total])
-        ds = self.loader.ds
-        if self.order == "morton":  # (group = 1) rows in spatial order, gathered by the ordering's last launch
-            ops.order_gather_batch(idx[:total], ds.shape, ds.axes, ds.axis_offset, ds.pixels, coords[:total],
-                                   target[:total], ws=self._order_ws)
-        else:
-            ds.batch(idx[:total], coords[:total], target[:total])
+        self.loader.ds.batch(idx[:total], coords[:total], target[:total])
         self._made[g % 2] = g
 
     def _view(self, k: int):

@@ -719,26 +719,6 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
 
 
 # --------------------------------------------------------------------------- batch producer
-def step_params_fill(host_block: "_lib.StepParams", lr, beta1, beta2, eps, step: int, grad_scale: float,
-                     sample_seed: int, sample_first: int):
-    """Fill a HOST mri_step_params with what adam_step / sample_indices derive from these arguments."""
-    _lib.call("mri_step_params_fill", C.byref(host_block), float(lr), float(beta1), float(beta2), float(eps),
-              int(step), float(grad_scale), int(sample_seed) & 0xFFFFFFFFFFFFFFFF, int(sample_first))
-
-
-def adam_step_dev(param, grad, exp_avg, exp_avg_sq, dev_params: torch.Tensor):
-    """adam_step with its prefactors read from a device-resident mri_step_params (graph replays)."""
-    _gpu(param, grad, exp_avg, exp_avg_sq)
-    _lib.call("mri_adam_step_dev", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
-              C.c_void_p(dev_params.data_ptr()), _stream())
-
-
-def sample_indices_dev(dev_params: torch.Tensor, lo: int, hi: int, n: int, out: torch.Tensor):
-    """sample_indices with (key, first) read from a device-resident mri_step_params (graph replays)."""
-    _lib.call("mri_sample_indices_dev", C.c_void_p(dev_params.data_ptr()), lo, hi, n, _ptr(out), _stream())
-    return out
-
-
 def sample_indices(seed: int, first: int, lo: int, hi: int, n: int, out=None, device="cuda"):
     if out is None:
         out = torch.empty(n, device=device, dtype=torch.int64)
@@ -746,51 +726,6 @@ def sample_indices(seed: int, first: int, lo: int, hi: int, n: int, out=None, de
     _lib.call("mri_sample_indices", C.c_uint64(seed & (2 ** 64 - 1)), first, lo, hi, n, _ptr(out),
               _stream())
     return out
-
-
-def order_batch_workspace(n: int, dim: int, device) -> torch.Tensor:
-    """Workspace of order_batch for batches of up to n rows (int64 tensor, 256-byte aligned by the allocator)."""
-    need = _lib.load().mri_order_batch_workspace_bytes(int(n), int(dim))
-    if need < 0:
-        raise ValueError(f"order_batch: bad n / dim ({n}, {dim})")
-    return torch.empty((need + 7) // 8, dtype=torch.int64, device=device)
-
-
-def order_batch(idx: torch.Tensor, shape: Sequence[int], ws: Optional[torch.Tensor] = None, stream=None):
-    """Reorders the flat voxel indices of ONE batch in place (mri_order_batch): Morton order over the axes of
-    `shape`, transposed inside blocks of 16384 rows -- the set is untouched, the order is the one the lookup and
-    the table-gradient kernels like best.  Deterministic."""
-    _gpu(idx)
-    if idx.dtype != torch.int64 or not idx.is_contiguous():
-        raise ValueError("order_batch: contiguous int64 indices")
-    n, dim = idx.numel(), len(shape)
-    if ws is None:
-        ws = order_batch_workspace(n, dim, idx.device)
-    shp = (C.c_int64 * dim)(*[int(s) for s in shape])
-    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
-    _lib.call("mri_order_batch", _ptr(idx), n, dim, shp, _ptr(ws), ws.numel() * 8, st)
-    return idx
-
-
-def order_gather_batch(idx: torch.Tensor, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],
-                       volume: Optional[torch.Tensor], coords=None, target=None, ws: Optional[torch.Tensor] = None):
-    """order_batch(idx) followed by gather_batch on the ordered indices, the gather done by the ordering's last launch
-    (mri_order_gather_batch): same indices, coordinates and targets."""
-    _gpu(idx, axes, volume, coords, target)
-    if idx.dtype != torch.int64 or not idx.is_contiguous():
-        raise ValueError("order_gather_batch: contiguous int64 indices")
-    n, dim = idx.numel(), len(shape)
-    if coords is None:
-        coords = torch.empty((n, dim), device=idx.device, dtype=torch.float32)
-    if target is None and volume is not None:
-        target = torch.empty((n, 1), device=idx.device, dtype=torch.float32)
-    if ws is None:
-        ws = order_batch_workspace(n, dim, idx.device)
-    shp = (C.c_int64 * dim)(*[int(s) for s in shape])
-    off = (C.c_int64 * dim)(*[int(o) for o in axis_offset])
-    _lib.call("mri_order_gather_batch", _ptr(idx), n, dim, shp, _ptr(axes), off, _ptr(volume), _ptr(coords), _ptr(target),
-              _ptr(ws), ws.numel() * 8, _stream())
-    return coords, target
 
 
 def gather_batch(idx, shape: Sequence[int], axes: torch.Tensor, axis_offset: Sequence[int],

@@ -716,26 +716,23 @@ class FusedStep:
 
 
 class SteadyLoop:
-    """The fused hash-grid + tiny-MLP training step (one GPU) queued with little host work per step.
+    """The fused hash-grid + tiny-MLP training step queued with little host work per step.
 
     Why: a step is ~12 kernel launches, a few memsets and a stream fork / join; queued op by op from Python
     through ctypes and torch's stream / event objects that is 0.2-0.55 ms of host time per step depending on the
-    box (tools/host_profile.py: 57 % of it interpreter and wrapper overhead) against 0.52 ms of GPU time -- on
-    a slow host the loop is HOST-bound (0.72 ms per step measured).  Two forms:
-      mode "native" (default): ONE call of the library's `mri_fused_step` per step, which composes the
-        same entry points in C (csrc/fused_step.hip);
-      mode "graph": one hipGraph per buffer parity, replayed (correct, kept for comparison -- on this runtime
-        a replay costs the host as much as the eager step).
-    Both are FusedStep.train_step's steady state with count_ahead:
+    box (tools/host_profile.py: 57 % of it interpreter and wrapper overhead) against 0.5 ms of GPU time -- on
+    a slow host the loop is HOST-bound (0.72 ms per step measured).  Here a step is ONE call of the library's
+    `mri_fused_step`, which composes the same entry points in C (csrc/fused_step.hip).  (Round 3 also built the
+    loop as hipGraph replays: correct, and on this runtime a replay cost the host as much as the eager step --
+    EXPERIMENTS.md; removed in round 4.)
+    It is FusedStep.train_step's steady state with count_ahead:
         side stream: produce batch k+1 (sample + gather) -> zero the next absmax buffer -> count batch k+1's
                      table-gradient records;    main: lookup -> decoder -> table gradient -> Adam;    join.
     The batch pipeline's two buffers, the two record workspaces and the two absmax buffers alternate with
-    the step's parity.  Graph mode reads what changes per step (Adam's bias-correction prefactors, the
-    shuffle position of the next batch) from a device-resident `mri_step_params` block refreshed before
-    every replay.  Same launches on the same data in the same order as the eager step: parameters are
+    the step's parity.  Same launches on the same data in the same order as the eager step: parameters are
     bit-identical (tests/test_gpu_round3.py::test_steady_loop_equals_the_eager_loop).
 
-    Eager steps (bench.py's event-bracketed sample steps, evaluation passes) can be mixed in: the Python
+    Eager steps (bench.py's --launch eager, evaluation passes) can be mixed in: the Python
     state of FusedStep / BatchPipeline / Adam is advanced as the eager step would have left it.  Two limits:
     (1) the native argument blocks hold raw device addresses of FusedStep's buffers; an eager step with ANOTHER
     batch size makes FusedStep reallocate them -- step_once() detects that and raises (capture() again);
@@ -763,31 +760,19 @@ class SteadyLoop:
             return "range shorter than a batch"
         return None
 
-    def __init__(self, step: "FusedStep", pipe: BatchPipeline, mode: str = "native", ring: int = 256):
+    def __init__(self, step: "FusedStep", pipe: BatchPipeline, mode: str = "native"):
         why = self.unsupported(step, pipe)
         if why:
             raise ValueError("SteadyLoop: " + why)
-        if mode == "graph" and pipe.order != "shuffled":
-            raise ValueError("SteadyLoop: ordered batches are queued natively or eagerly, not as graph replays")
-        if mode not in ("native", "graph"):
-            raise ValueError("mode: native or graph")
-        if mode == "graph" and (not step.count_ahead or step.world != 1):
-            raise ValueError("SteadyLoop: the graph form needs count_ahead and one GPU")
+        if mode != "native":
+            raise ValueError("SteadyLoop: one form, mode='native' (the hipGraph-replay form was removed in round 4)")
         self.step, self.pipe, self.mode = step, pipe, mode
         self._wmap = self._amap = None
         self._after_eager = True
         self._join_pending = False
-        if mode == "graph":
-            dev = step.flat.param.device
-            self.dev_params = torch.zeros(2, 48, dtype=torch.uint8, device=dev)
-            self._host = torch.zeros(ring, 48, dtype=torch.uint8).pin_memory()
-            self._host_struct = [_lib.StepParams.from_address(self._host[i].data_ptr()) for i in range(ring)]
-            self._host_event = [None] * ring
-            self._slot = 0
-            self.graphs = [None, None]
-        else:
-            self._args = [None, None]
-            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self._args = [None, None]
+        self._pins = [None, None]
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
 
     # -- the buffers of a step of parity p (batch k in pipeline buffer p) --------------------------------
     def _buffers(self, p: int):
@@ -800,29 +785,6 @@ class SteadyLoop:
         am_p = st._absmax[self._amap[p]] if st._absmax is not None else None
         am_q = st._absmax[self._amap[q]] if st._absmax is not None else None
         return n, coords_p, target_p, idx_q, coords_q, target_q, ws_p, ws_q, am_p, am_q
-
-    def _enqueue(self, p: int):
-        """Graph mode: one step's launches, under capture."""
-        st = self.step
-        ld, ds, enc = self.pipe.loader, self.pipe.loader.ds, st.encoder
-        n, coords_p, target_p, idx_q, coords_q, target_q, ws_p, ws_q, am_p, am_q = self._buffers(p)
-        main = torch.cuda.current_stream()
-        st._side.wait_stream(main)
-        with torch.cuda.stream(st._side):
-            ops.sample_indices_dev(self.dev_params[p], ld.lo, ld.hi, n, idx_q)
-            ds.batch(idx_q, coords_q, target_q)
-            if am_q is not None:
-                am_q.zero_()
-            ops.hashgrid_backward_prepare(enc.desc, coords_q, st.bwd_method, st._side, ws=ws_q)
-        w = st._workspace(n, True)
-        ops.hashgrid_forward(enc.desc, coords_p, enc.table.data, out=w["enc"], feature_major=True)
-        ops.tiny_mlp_train(w["enc"], target_p, st.tiny["params"], st.tiny["grads"], st.loss, d_x=w["d_enc"],
-                           grad_divisor=1.0, overwrite=True, dx_absmax=am_p)
-        ops.hashgrid_backward(enc.desc, coords_p, w["d_enc"], st._table_grad, feature_major=True,
-                              method=st.bwd_method, prepared=True, overwrite=True, ws=ws_p, level_absmax=am_p)
-        f = st.flat
-        ops.adam_step_dev(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.dev_params[p])
-        main.wait_stream(st._side)
 
     def _native_args(self, p: int) -> "_lib.FusedStepArgs":
         """Native mode: the argument block of parity p; everything but the per-step scalars is fixed."""
@@ -861,8 +823,6 @@ class SteadyLoop:
         for d in range(ds.dim_in):
             a.shape[d], a.axis_offset[d] = int(ds.shape[d]), int(ds.axis_offset[d])
         a.axes, a.volume = ptr(ds.axes), ptr(ds.pixels)
-        if self.pipe.order == "morton":  # the next batch's rows in spatial order (ops.order_gather_batch)
-            a.order_ws, a.order_ws_bytes = ptr(self.pipe._order_ws), self.pipe._order_ws.numel() * 8
         a.stream_side = st._side.cuda_stream
         a.ev_fork, a.ev_join = self._ev_fork.cuda_event, self._ev_join.cuda_event
         # The struct holds RAW pointers: every tensor behind one is pinned here (kept alive) with the address it
@@ -891,8 +851,7 @@ class SteadyLoop:
 
     def capture(self, warm_steps: int = 4):
         """`warm_steps` eager steps (at least two before the first capture: they allocate every workspace and
-        leave the next batch produced and counted), then the per-parity graphs (graph mode) or argument
-        blocks (native mode)."""
+        leave the next batch produced and counted), then the per-parity argument blocks."""
         st, pipe = self.step, self.pipe
         for _ in range(warm_steps):  # (0: the caller's own eager steps have established the steady state)
             self.eager_step()
@@ -913,18 +872,11 @@ class SteadyLoop:
             st._absmax_clean[nxt] = True
         st._batch_event = None
         torch.cuda.synchronize()
-        if self.mode == "graph":
-            for p in (p0, 1 - p0):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._enqueue(p)
-                self.graphs[p] = g
-        else:
-            self._ev_fork.record()  # materialises the handles
-            self._ev_join.record()
-            torch.cuda.synchronize()
-            self._pins = [None, None]
-            self._args = [self._native_args(0), self._native_args(1)]
+        self._ev_fork.record()  # materialises the handles
+        self._ev_join.record()
+        torch.cuda.synchronize()
+        self._pins = [None, None]
+        self._args = [self._native_args(0), self._native_args(1)]
         self._after_eager, self._join_pending = True, False
         return self
 
@@ -954,9 +906,9 @@ class SteadyLoop:
         self._event_pool = pool
 
     def step_once(self, sample: bool = False):
-        """Queue the current step; returns the (device) loss scalar.  `sample` (native mode): bracket the four
-        phases with timing events INSIDE the library call and file them under FusedStep.phase_events (an
-        eager sample step between queued ones stalls the queue for over a millisecond on this runtime)."""
+        """Queue the current step; returns the (device) loss scalar.  `sample`: bracket the four phases with
+        timing events INSIDE the library call and file them under FusedStep.phase_events (an eager sample
+        step between queued ones stalls the queue for over a millisecond on this runtime)."""
         st, pipe = self.step, self.pipe
         k = pipe.k
         p = k % 2
@@ -972,53 +924,41 @@ class SteadyLoop:
         # what changes per step: Adam's step number, the shuffle position of the NEXT batch
         e, b = divmod(k + 1, pipe.per_epoch)
         seed, first = ld.seed + 7919 * (pipe.epoch0 + e), ld.span(b)[0]
-        if self.mode == "graph":
-            i = self._slot = (self._slot + 1) % len(self._host_struct)
-            if self._host_event[i] is not None:
-                self._host_event[i].synchronize()  # (a ring of 256: the copy of 256 steps ago is long done)
-            ops.step_params_fill(self._host_struct[i], opt.param_groups[0]["lr"], opt.betas[0], opt.betas[1],
-                                 opt.eps, opt.step_count + 1, opt.grad_scale, seed, first)
-            self.dev_params[p].copy_(self._host[i], non_blocking=True)
-            ev = self._host_event[i] or torch.cuda.Event()
-            ev.record()
-            self._host_event[i] = ev
-            self.graphs[p].replay()
-        else:
-            a = self._args[p]
-            self._check_pins(p)
-            a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
-            a.lr = opt.param_groups[0]["lr"]
-            a.join_pending = 1 if self._join_pending else 0
-            a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
-            evs = None
-            if sample and st.phase_events is not None:
-                pool = getattr(self, "_event_pool", None)
-                if pool:
-                    evs = pool.pop()
-                else:
-                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-                    for ev in evs:
-                        ev.record()  # materialises the handle (re-recorded inside the call)
-                for i, ev in enumerate(evs):
-                    a.ev_phase[i] = ev.cuda_event
-            _lib.call("mri_fused_step", C.byref(a))
-            if evs is not None:
-                for i, name in enumerate(self.PHASES):
-                    if st.world == 1 or name != "adam":  # (several ranks: Adam is queued below, behind the reduction)
-                        st.phase_events.setdefault(name, []).append((evs[i], evs[i + 1]))
-                    a.ev_phase[i] = None
-                a.ev_phase[4] = None
-            self._join_pending = True
-            if st.world > 1:  # data parallel, plain form: ONE reduction of the flat gradient, then Adam
-                st.last_group_bytes = [st.flat.grad.numel() * 4]
-                timed = sample and st.phase_events is not None
-                saved, st.phase_events = st.phase_events, (st.phase_events if timed else None)
-                with st._phase("all_reduce"), st._phase("reduce_wait_0"):
-                    parallel.all_reduce_sum(st.flat.grad)
-                with st._phase("adam"):
-                    opt.step()
-                st.phase_events = saved
-                opt.step_count -= 1  # (counted below, as for one rank)
+        a = self._args[p]
+        self._check_pins(p)
+        a.step, a.seed, a.first = opt.step_count + 1, seed & 0xFFFFFFFFFFFFFFFF, first
+        a.lr = opt.param_groups[0]["lr"]
+        a.join_pending = 1 if self._join_pending else 0
+        a.stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+        evs = None
+        if sample and st.phase_events is not None:
+            pool = getattr(self, "_event_pool", None)
+            if pool:
+                evs = pool.pop()
+            else:
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                for ev in evs:
+                    ev.record()  # materialises the handle (re-recorded inside the call)
+            for i, ev in enumerate(evs):
+                a.ev_phase[i] = ev.cuda_event
+        _lib.call("mri_fused_step", C.byref(a))
+        if evs is not None:
+            for i, name in enumerate(self.PHASES):
+                if st.world == 1 or name != "adam":  # (several ranks: Adam is queued below, behind the reduction)
+                    st.phase_events.setdefault(name, []).append((evs[i], evs[i + 1]))
+                a.ev_phase[i] = None
+            a.ev_phase[4] = None
+        self._join_pending = True
+        if st.world > 1:  # data parallel, plain form: ONE reduction of the flat gradient, then Adam
+            st.last_group_bytes = [st.flat.grad.numel() * 4]
+            timed = sample and st.phase_events is not None
+            saved, st.phase_events = st.phase_events, (st.phase_events if timed else None)
+            with st._phase("all_reduce"), st._phase("reduce_wait_0"):
+                parallel.all_reduce_sum(st.flat.grad)
+            with st._phase("adam"):
+                opt.step()
+            st.phase_events = saved
+            opt.step_count -= 1  # (counted below, as for one rank)
         # what an eager step would have left behind
         opt.step_count += 1
         pipe._made[(k + 1) % 2] = k + 1
@@ -1039,18 +979,13 @@ class SteadyLoop:
             self._join_pending = False
 
 
-def GraphedLoop(step, pipe, **kw):
-    """SteadyLoop in hipGraph-replay form (see there)."""
-    return SteadyLoop(step, pipe, mode="graph", **kw)
-
-
 class Trainer:
     """fit / predict with the subset of `pl.Trainer` the reference launcher uses."""
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accelerator: str = "gpu",
                  precision: int = 32, log_every: int = 0, distributed: bool = True,
                  accumulate_grad_batches=None, dp_mode: str = "all_reduce", grad_buckets: int = 1,
-                 batch_group: int = 1, native_steps: bool = True, batch_order: str = "shuffled"):
+                 batch_group: int = 1, native_steps: bool = True):
         """`accumulate_grad_batches`: an int k (gradients of k consecutive batches are summed,
         each scaled by 1/k, before one Adam step -- what `pl.Trainer(accumulate_grad_batches=k)`
         does, reference launcher.py:159-161) or a mapping {epoch: k} (k from that epoch on, the
@@ -1068,7 +1003,6 @@ class Trainer:
         self.grad_buckets = int(grad_buckets)  # level groups of the table gradient's reduction, see there
         self.batch_group = int(batch_group)    # batches per launch of the on-device producer (BatchPipeline)
         self.native_steps = bool(native_steps)  # queue steady-state steps with one library call (SteadyLoop)
-        self.batch_order = batch_order  # order of a batch's rows on the device (BatchPipeline: "shuffled" / "morton")
         self.rank, self.world = 0, 1
         if distributed:
             rank, world, _ = parallel.env_world()
@@ -1126,7 +1060,7 @@ class Trainer:
         if self.fused is not None and isinstance(train_dataloaders, DeviceLoader) \
                 and len(train_dataloaders) > 0:
             train_dataloaders.set_epoch(0)
-            pipe = BatchPipeline(train_dataloaders, group=self.batch_group, order=self.batch_order)
+            pipe = BatchPipeline(train_dataloaders, group=self.batch_group)
             self.fused.forget_ahead()  # a new pipeline: nothing counted earlier is about its batches
         # one library call per step (SteadyLoop, native form) once the first eager steps have set up the
         # steady state -- same launches on the same data, bit-identical parameters

@@ -91,10 +91,7 @@ def test_every_entry_point_rejects_null_buffers_before_touching_the_device(lib):
         "mri_siren_forward_loss": (None, None, 8, 8, 3, 256, 5, None, None, 30.0, 30.0, 1.0, None, None)
                                   + (None,) * 7 + (0, None),
         "mri_sample_indices": (1, 0, 10, 5, 4, None, None),
-        "mri_step_params_fill": (None, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, 7, 0),
         "mri_fused_step": (None,),
-        "mri_adam_step_dev": (None, None, None, None, 8, None, None),
-        "mri_sample_indices_dev": (None, 0, 10, 4, None, None),
         "mri_gather_batch": (None, 4, 3, None, None, None, None, None, None, None),
     }
     for name, args in calls.items():
@@ -110,26 +107,6 @@ def test_every_entry_point_rejects_null_buffers_before_touching_the_device(lib):
     assert h.mri_siren_forward_workspace_bytes(64, 1) == 0
     assert h.mri_siren_forward_workspace_bytes(96, 3) == -1
     assert h.mri_siren_backward_workspace_bytes(1 << 12, 256, 5) > h.mri_siren_forward_workspace_bytes(256, 5)
-
-
-def test_step_params_match_the_by_value_entry_points(lib):
-    """mri_step_params_fill (host): the prefactors mri_adam_step derives from (lr, betas, eps, step) -- double
-    arithmetic, then float -- and the struct layout the kernels read."""
-    import math
-    import struct
-    assert C.sizeof(lib.StepParams) == 48
-    assert C.sizeof(lib.FusedStepArgs) == lib.load().mri_fused_step_args_bytes()  # the binding's layout is the header's
-    blank = lib.FusedStepArgs()
-    assert lib.load().mri_fused_step(C.byref(blank)) == -1 and "NULL" in lib.load().mri_last_error().decode()
-    p = lib.StepParams()
-    lib.call("mri_step_params_fill", C.byref(p), 5e-3, 0.9, 0.999, 1e-8, 7, 0.5, 1337, 262144)
-    f32 = lambda v: struct.unpack("f", struct.pack("f", v))[0]  # noqa: E731
-    assert p.one_minus_b1 == f32(1.0 - 0.9) and p.b2 == f32(0.999) and p.one_minus_b2 == f32(1.0 - 0.999)
-    assert p.neg_step_size == f32(-(5e-3 / (1.0 - 0.9 ** 7))) and p.bc2_sqrt == f32(math.sqrt(1.0 - 0.999 ** 7))
-    assert p.eps == f32(1e-8) and p.grad_scale == 0.5 and p.sample_first == 262144 and p.sample_key != 1337
-    q = lib.StepParams()
-    lib.call("mri_step_params_fill", C.byref(q), 5e-3, 0.9, 0.999, 1e-8, 7, 0.5, 1338, 0)
-    assert q.sample_key != p.sample_key
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):

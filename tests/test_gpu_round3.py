@@ -376,17 +376,12 @@ def test_grouped_batch_production_gives_the_same_batches(amd, steps):
             assert torch.equal(c0, c1) and torch.equal(t0, t1), (group, k)
 
 
-# --------------------------------------------------------------------------- hipGraph replays
-@pytest.mark.parametrize("hidden,records,order,mode", [
-    (128, 0, "shuffled", "native"), (64, 0, "shuffled", "native"), (128, 1, "shuffled", "native"),
-    (128, 0, "shuffled", "graph"), (64, 0, "shuffled", "graph"), (128, 1, "shuffled", "graph"),
-    (128, 0, "morton", "native"), (64, 0, "morton", "native")])  # (ordered batches: native or eager, never graph replays)
-def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
-    """trainer.SteadyLoop queues the fused step with ONE library call (`mri_fused_step`, mode native) or replays
-    it as one hipGraph per buffer parity (mode graph: Adam's prefactors and the next batch's shuffle position
-    read from a device-resident mri_step_params block): after 70 steps over several epochs -- eager steps mixed
-    in, as bench.py's event-bracketed sample steps are -- parameters, both Adam moments and the step count
-    equal the eager loop's bit for bit."""
+# --------------------------------------------------------------------------- the natively queued step
+@pytest.mark.parametrize("hidden,records", [(128, 0), (64, 0), (128, 1)])
+def test_steady_loop_equals_the_eager_loop(amd, hidden, records):
+    """trainer.SteadyLoop queues the fused step with ONE library call (`mri_fused_step`): after 70 steps over
+    several epochs -- eager steps mixed in -- parameters, both Adam moments and the step count equal the eager
+    loop's bit for bit.  (Round 3's hipGraph-replay form and its spatially ordered batches were removed in round 4.)"""
     amd.lib.set_option("bwd_records", records)
     dev = torch.device("cuda", 0)
     vol = amd.datamodules.phantom_volume((40, 40, 40), device=dev)
@@ -397,10 +392,8 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
         net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=hidden, n_layers=3, activation=torch.nn.ReLU,
                                  batch_norm=False, final_activation=False, lr=5e-3).cuda()
         step = amd.trainer.FusedStep(net, net.configure_optimizers())
-        if mode == "graph":
-            step.count_ahead = True  # (the native form also serves the 64-wide decoder's default: counted in-step)
         loader = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=True, seed=1337)
-        return net, step, amd.datamodules.BatchPipeline(loader, order=order)
+        return net, step, amd.datamodules.BatchPipeline(loader)
 
     n_steps = 70
     _, eager, pipe_e = build()
@@ -410,7 +403,7 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
         losses_e.append(float(eager.train_step(c, t, pipe_e.produce_next)))
         pipe_e.advance()
     _, st, pipe_g = build()
-    loop = amd.trainer.SteadyLoop(st, pipe_g, mode=mode).capture(warm_steps=4)
+    loop = amd.trainer.SteadyLoop(st, pipe_g).capture(warm_steps=4)
     done = 4
     assert pipe_g.k == done and st.opt.step_count == done
     losses_g = []
@@ -435,9 +428,8 @@ def test_steady_loop_equals_the_eager_loop(amd, hidden, records, order, mode):
     assert amd.trainer.SteadyLoop.unsupported(st2, pipe2) is None
     short = amd.datamodules.DeviceLoader(ds, 4096, shuffle=True, drop_last=False, seed=1)
     assert "full" in amd.trainer.SteadyLoop.unsupported(st, amd.datamodules.BatchPipeline(short))
-    if order == "morton":
-        with pytest.raises(ValueError, match="graph"):
-            amd.trainer.SteadyLoop(st2, pipe2, mode="graph")
+    with pytest.raises(ValueError, match="native"):
+        amd.trainer.SteadyLoop(st2, pipe2, mode="graph")
 
 
 def test_trainer_fit_with_native_steps_equals_eager_fit(amd):
@@ -468,114 +460,3 @@ def test_trainer_fit_with_native_steps_equals_eager_fit(amd):
     assert tr.global_step == 2 * 11 and bool(torch.isfinite(tr.fused.flat.param).all())
 
 
-# --------------------------------------------------------------------------- the order of a batch's rows
-def _morton_cells(idx, shape, cell):
-    """Cell number (at `cell` voxels per axis) of flat C-order voxel indices."""
-    out, rest = [], idx.clone()
-    for extent in reversed(shape):
-        out.append((rest % extent) // cell)
-        rest = rest // extent
-    key = torch.zeros_like(idx)
-    for c in out:
-        key = key * 4096 + c
-    return key
-
-
-@pytest.mark.parametrize("shape,n", [((256, 256, 256), 1 << 18), ((352, 352, 6, 15), 100_000), ((40, 40, 40), 4096),
-                                     ((64, 48), 1000), ((33, 7, 5), 50)])
-def test_order_batch_is_a_deterministic_permutation(amd, shape, n):
-    """ops.order_batch (mri_order_batch) re-orders the flat voxel indices of a batch: the SET is untouched (the
-    shuffle decides which voxels a batch holds), the order is the same every run, batches shorter than a
-    transposition block and of other dimensions pass, and in a full block a wave's 64 rows come from 64 different
-    neighbourhoods while neighbouring rows of consecutive waves are close (what the kernels want, see the entry
-    point's comment)."""
-    dev = torch.device("cuda", 0)
-    total = 1
-    for e in shape:
-        total *= e
-    g = torch.Generator(device="cpu").manual_seed(5)
-    idx = torch.randperm(total, generator=g)[:n].to(dev)
-    a, b = idx.clone(), idx.clone()
-    amd.ops.order_batch(a, shape)
-    amd.ops.order_batch(b, shape)
-    torch.cuda.synchronize()
-    assert torch.equal(a, b), "two runs order the same batch differently"
-    assert torch.equal(torch.sort(a).values, torch.sort(idx).values), "the batch's set changed"
-    # the documented order, restated: stable sort on the 12 highest bits of the Morton key (8 bits per axis, last axis
-    # in the lowest bit, at most four axes), then the transposition inside full blocks of 16384 rows
-    used = min(len(shape), 4)
-    pos, rest = [], idx.clone()
-    for extent in reversed(shape):
-        pos.append(((rest % extent) * 256) // extent)
-        rest = rest // extent
-    pos = pos[::-1][:used]
-    key = torch.zeros_like(idx)
-    for bit in range(7, -1, -1):
-        for d in range(used):
-            key = key * 2 + ((pos[d] >> bit) & 1)
-    if 8 * used > 12:
-        key = key >> (8 * used - 12)
-    ordered = idx[torch.sort(key, stable=True).indices]
-    q = torch.arange(n, device=dev)
-    inner = q % 16384
-    full = (q - inner + 16384) <= n
-    place = torch.where(full, q - inner + (inner % 256) * 64 + inner // 256, q)
-    want = torch.empty_like(ordered)
-    want[place] = ordered
-    assert torch.equal(a, want), "not the documented order"
-    if n >= 16384 and len(shape) == 3:
-        assert not torch.equal(a, idx)
-        cells = _morton_cells(a[:16384], shape, 16).reshape(256, 64)  # [wave][lane] of the first block
-        per_wave = torch.tensor([len(torch.unique(cells[w])) for w in range(0, 256, 17)])
-        assert int(per_wave.min()) >= 48, per_wave  # a wave: (almost) as many 16-voxel cells as lanes
-        same = (cells[1:] == cells[:-1]).float().mean()  # lane l of waves w, w + 1: Morton neighbours
-        assert float(same) > 0.8, float(same)
-
-
-def test_order_gather_batch_equals_order_then_gather(amd):
-    """ops.order_gather_batch (the ordering's last launch gathers the rows) gives the indices, coordinates and targets
-    of ops.order_batch followed by the data set's gather, on a 3-D and the 4-D sample shape."""
-    dev = torch.device("cuda", 0)
-    for shape, n in (((48, 40, 36), 20000), ((22, 20, 6, 15), 33333)):
-        vol = torch.rand(shape, device=dev)
-        ds = amd.datamodules.MriImage(volume=vol, device=dev)
-        idx = torch.randperm(len(ds), device=dev)[:n].contiguous()
-        a = idx.clone()
-        amd.ops.order_batch(a, ds.shape)
-        c0, t0 = ds.batch(a)
-        b = idx.clone()
-        c1, t1 = amd.ops.order_gather_batch(b, ds.shape, ds.axes, ds.axis_offset, ds.pixels)
-        torch.cuda.synchronize()
-        assert torch.equal(a, b) and torch.equal(c0, c1) and torch.equal(t0, t1)
-
-
-def test_ordered_batch_gives_the_same_step(amd):
-    """A fused training step on a batch in Morton order and on the same rows in shuffle order: predictions and
-    the gradient of the encoding are row-wise, the table gradient an exact sum -- bit-identical tables'
-    gradients --, loss and decoder gradients are sums in another order (1e-5 of their largest entry)."""
-    dev = torch.device("cuda", 0)
-    vol = amd.datamodules.phantom_volume((64, 64, 64), device=dev)
-    ds = amd.datamodules.MriImage(volume=vol, device=dev)
-    loader = amd.datamodules.DeviceLoader(ds, 1 << 15, shuffle=True, drop_last=True, seed=11)
-    grads = []
-    for order in ("shuffled", "morton"):
-        torch.manual_seed(1337)
-        net = amd.models.HashMLP(3, 16, 2, 15, 16, 512, dim_hidden=128, n_layers=3, activation=torch.nn.ReLU,
-                                 batch_norm=False, final_activation=False, lr=5e-3).cuda()
-        with torch.no_grad():
-            net.encoder.table.uniform_(-0.5, 0.5)
-        step = amd.trainer.FusedStep(net, net.configure_optimizers())
-        pipe = amd.datamodules.BatchPipeline(loader, order=order)
-        c, t = pipe.current()
-        loss = float(step.train_step(c, t))  # (the gradients stay in the flat buffer behind the Adam step)
-        torch.cuda.synchronize()
-        grads.append((loss, step.flat.grad.clone(), c.clone()))
-    (l0, g0, c0), (l1, g1, c1) = grads
-    key = lambda c: torch.sort((c * torch.tensor([1.0, 64.0, 4096.0], device=dev)).sum(1).double()).values  # noqa: E731
-    assert not torch.equal(c0, c1) and torch.equal(key(c0), key(c1))
-    assert abs(l0 - l1) <= 1e-5 * abs(l0)
-    diff = (g0 - g1).abs()
-    assert float(diff.max()) <= 1e-5 * float(g0.abs().max())
-    table = step.encoder.table
-    lo = (table.data_ptr() - step.flat.param.data_ptr()) // 4
-    assert torch.equal(g0[lo:lo + table.numel()], g1[lo:lo + table.numel()]), "table gradients differ in bits"
