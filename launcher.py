@@ -63,6 +63,9 @@ def parse_args(argv=None):
     p.add_argument("--unsafe_checkpoint", action="store_true",
                    help="read --checkpoint_path with the unrestricted unpickler (Lightning files holding "
                         "callback objects); executes code from the file")
+    p.add_argument("--accelerator", choices=("auto", "gpu", "cpu"), default="auto",
+                   help="auto: the MI355X path if a GPU is visible, else the PyTorch-CPU plumbing mode (SirenNet only; "
+                        "reference launcher.py:157: accelerator='gpu' if torch.cuda.is_available() else 'cpu')")
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--max_steps", type=int, default=-1)
     p.add_argument("--log_every", type=int, default=50)
@@ -99,10 +102,20 @@ def main(argv=None):
     from mri_interpolation_amd import _lib, config as cfg, datamodules, models, nifti, parallel
     from mri_interpolation_amd.trainer import Trainer, psnr
 
-    _lib.load()
+    # reference launcher.py:157: the GPU when there is one, else the CPU.  The CPU mode is plumbing (BASELINE config 1):
+    # plain PyTorch, SirenNet only (mri_interpolation_amd/cpu_path.py); the MI355X path itself has no CPU form and a
+    # GPU run without its library still fails loudly
+    use_cpu = args.accelerator == "cpu" or (args.accelerator == "auto" and not torch.cuda.is_available())
     torch.manual_seed(1337)  # reference launcher.py:30
-    rank, world, local = parallel.init()
-    torch.cuda.set_device(local)
+    if use_cpu:
+        if (args.model_class or "HashMLP") != "SirenNet":
+            raise SystemExit(f"--accelerator cpu trains SirenNet only (BASELINE config 1); {args.model_class or 'HashMLP'} "
+                             "runs on the MI355X path (--accelerator gpu)")
+        rank, world, local = 0, 1, 0
+    else:
+        _lib.load()
+        rank, world, local = parallel.init()
+        torch.cuda.set_device(local)
 
     wants_hash = (args.model_class or "HashMLP") == "HashMLP"
     config = cfg.HashConfig() if wants_hash else cfg.BaseConfig()
@@ -111,7 +124,7 @@ def main(argv=None):
         config.enco_config = cfg.load_json(enco_path)  # reference launcher.py:73-74
     overrides = {k: v for k, v in vars(args).items()
                  if k not in ("synthetic", "tiny_mlp", "out_dir", "max_steps", "log_every",
-                              "resume_optimizer", "restore_lr", "unsafe_checkpoint",
+                              "resume_optimizer", "restore_lr", "unsafe_checkpoint", "accelerator",
                               "enco_config_path", "holdout_odd_frames", "base_resolution",
                               "finest_resolution")}
     cfg.apply_overrides(config, overrides)
@@ -143,6 +156,8 @@ def main(argv=None):
                          f"{config.dim_in}-D volume (SURVEY.md Q7): pass --slice, --tiny_mlp or "
                          "--base_resolution / --finest_resolution with one value per axis")
     config.norm_siren = config.model_class in ("SirenNet", "ModulatedSirenNet")
+    if use_cpu:
+        return main_cpu(args, config, volume)
 
     model = build_model(config, models).cuda()
     if config.checkpoint_path:  # reference launcher.py:97-117 (model_cls.load_from_checkpoint)
@@ -232,6 +247,52 @@ def main(argv=None):
     config.coords_per_second = trainer.throughput[-1] if trainer.throughput else None
     config.export_to_txt(out_dir)
     print(f"trained {trainer.global_step} steps in {train_seconds:.2f} s "
+          f"({config.coords_per_second:.3e} coord-samples/s), PSNR {quality:.2f} dB -> {out_dir}")
+
+
+def main_cpu(args, config, volume):
+    """Train, predict and write the artefacts without a GPU: plain PyTorch on the CPU (cpu_path.py), SirenNet."""
+    import numpy as np
+    import torch
+    from mri_interpolation_amd import checkpoint, cpu_path, models, nifti
+    model = build_model(config, models)
+    if config.checkpoint_path:
+        checkpoint.load(config.checkpoint_path, model, allow_pickle=args.unsafe_checkpoint)
+    coords = cpu_path.grid_coords(volume.shape, norm_siren=True)
+    pixels = cpu_path.normalised_pixels(volume, norm_siren=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.time()
+    losses, steps = cpu_path.fit(model, coords, pixels, config.batch_size, config.epochs, seed=config.seed,
+                                 max_steps=args.max_steps, log_every=args.log_every)
+    train_seconds = time.time() - t0
+    out_dir = args.out_dir
+    if out_dir is None:
+        base, version = os.path.join(ROOT, "lightning_logs"), 0
+        while os.path.exists(os.path.join(base, f"version_{version}")):
+            version += 1
+        out_dir = os.path.join(base, f"version_{version}")
+        config.log = str(version)
+    os.makedirs(os.path.join(out_dir, "checkpoints"), exist_ok=True)
+    checkpoint.save(os.path.join(out_dir, "checkpoints", f"epoch={config.epochs - 1}-step={steps}.ckpt"), model,
+                    epoch=config.epochs - 1, global_step=steps)
+    pred = cpu_path.predict(model, coords, config.batch_size)
+    quality = cpu_path.psnr((pred + 1) / 2, (pixels + 1) / 2)
+    im = np.array(pred.reshape(config.image_shape).numpy(), dtype=np.float32)
+    if im.ndim == 2:
+        np.save(os.path.join(out_dir, "pred.npy"), im)
+    nifti.save(im, os.path.join(out_dir, "pred.nii.gz"))
+    for shape in config.interp_shapes:
+        if len(shape) != config.dim_in:
+            print(f"skip interpolation shape {shape}: volume is {config.dim_in}-D")
+            continue
+        interp = cpu_path.predict(model, cpu_path.grid_coords(shape, norm_siren=True), config.batch_size)
+        nifti.save(np.array(interp.reshape(shape).numpy(), dtype=np.float32),
+                   os.path.join(out_dir, f"interpolation{tuple(shape)}.nii.gz"))
+    config.train_seconds, config.psnr_db, config.accelerator = train_seconds, quality, "cpu"
+    config.coords_per_second = steps * config.batch_size / max(train_seconds, 1e-9)
+    config.final_loss = losses[-1] if losses else None
+    config.export_to_txt(out_dir)
+    print(f"trained {steps} steps on {torch.get_num_threads()} CPU threads in {train_seconds:.2f} s "
           f"({config.coords_per_second:.3e} coord-samples/s), PSNR {quality:.2f} dB -> {out_dir}")
 
 
