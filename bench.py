@@ -39,7 +39,7 @@ MFMA_X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6
 # f32 rounding of an f32 evaluation; the matrix products reach that on the bf16 pipe
 ARITHMETIC = ("f32 values and f32 accumulation everywhere; matrix products as six bf16 MFMAs per product on "
               "operands split EXACTLY into three bf16 terms (per-product error below f32 rounding, measured "
-              "equal to v_mfma_f32_32x32x2_f32: DESIGN.md 4.9, tests/test_bf16x3_cpu.py); hash / gather / "
+              "equal to v_mfma_f32_32x32x2_f32: DESIGN.md 4.4, tests/test_bf16x3_cpu.py); hash / gather / "
               "Adam in plain f32; table gradient: ")
 # the table-gradient records (mri_set_option("bwd_records")): what is added up, said in the line
 RECORDS = {
@@ -669,7 +669,7 @@ def main():
     # Device state.  After idle an MI355X takes about a second under load to settle its clocks: a 20-step leg that
     # starts cold reads 4 % slower than the same leg a second later (0.541 against 0.518 ms per step, the decoder
     # 0.200 against 0.181; any GPU work warms it, the model's state does not matter, and an idle gap of a few
-    # hundred ms -- the first process on a box loading the kernels of the PSNR pass -- cools it again: DESIGN.md 5).
+    # hundred ms -- the first process on a box loading the kernels of the PSNR pass -- cools it again: DESIGN.md 5, EXPERIMENTS.md Part II).
     # Every timed leg of a run must see the same device: on one GPU the quality leg's TRAINING steps (psnr_steps
     # steps of this very workload, ~1 s) run first, the timed legs follow them without a gap, and the PSNR is
     # evaluated at the end from the parameters saved at psnr_steps; with several ranks (where a leg may hang and

@@ -421,7 +421,7 @@ int mri_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * All pointers are device pointers except `grid`, `shape`, `axis_offset` (host); streams and events are the
  * caller's.  Feature-major (2 L, n) blocks `enc`, `d_enc`.  Same launches on the same data as the separate
  * calls: results are bit-identical.  Why: queued op by op from an interpreter the step costs more host
- * time than GPU time on a slow host (DESIGN.md 5).  One launch fewer than the separate calls: with n_params > 0
+ * time than GPU time on a slow host (DESIGN.md 4.7).  One launch fewer than the separate calls: with n_params > 0
  * the table gradient's last conversion (int64 sums -> f32, bin_finalize_kernel) is done by the Adam kernel as it
  * fetches the gradient (the same expression: the same bits) -- `d_table` then does NOT hold the gradient of those
  * levels after the call. */

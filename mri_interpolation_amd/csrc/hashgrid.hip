@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(
   const Cell<D> c = locate<D>(x, live ? i : n - 1, tab.res[level]);
   float p0 = 0.0f, p1 = 0.0f;
   // (cache-policy bits on these gathers -- sc0, sc1, sc0 sc1 through inline-asm loads -- measured no
-  // change, 0.108 ms in every form on one box; nt: 0.303)
+  // change, 0.108 ms in every form on one box; nt: 0.303, EXPERIMENTS.md Part II 4.5)
   {
 #pragma unroll
     for (int nb = 0; nb < (1 << (D - 1)); ++nb) {

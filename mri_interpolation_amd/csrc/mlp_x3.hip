@@ -24,7 +24,7 @@
 //
 // A 32-row tile takes three workgroup barriers (see the schedule in the kernel); two waves per SIMD
 // cover each other's LDS latencies, and VALU epilogues (bias, ReLU, the exact split: 5.5
-// instructions per element) of one wave run beside the other's MFMAs.  DESIGN.md 4.9 has the
+// instructions per element) of one wave run beside the other's MFMAs.  DESIGN.md 4.3-4.4 and EXPERIMENTS.md (Part II 4.9) have the
 // measurements and what was tried.
 #include <algorithm>
 

@@ -95,7 +95,7 @@ class FusedStep:
         # one rank, no accumulation: the table's Adam update runs where its gradient is complete
         # (mri_hashgrid_backward_adam); the table part of flat.grad is then NOT produced.  Bit-identical
         # to the two launches; measured 0.574 -> 0.562 ms on config 4 but 0.451 -> 0.460 on config 2
-        # and 0.869 -> 0.885 on config 5: off by default
+        # and 0.869 -> 0.885 on config 5 (EXPERIMENTS.md Part II 4.2): off by default
         self.fuse_table_adam = False
         self._table_stepped = False
         # Data parallel: the table gradient is produced level by level, so its reduction is cut
@@ -155,7 +155,7 @@ class FusedStep:
         # ALUs, so beside the decoder's two MFMA waves per SIMD the lookup's ~150 vector
         # instructions per (coordinate, level) barely issue, and the 64 registers the decoder leaves
         # free hold 2 lookup waves per SIMD instead of 8 -- the lookup takes 0.49 ms instead of
-        # 0.10 and the decoder waits for it.  Off by default.
+        # 0.10 and the decoder waits for it (EXPERIMENTS.md Part II 4.7).  Off by default.
         self.overlap_forward = False
         self._ready = None       # uint64 slice counters: only ever grow
         self._ready_total = 0    # what a complete slice's counter holds after this step

@@ -279,7 +279,7 @@ def _overlap_equals_sequential(amd, dim, n):
         net.encoder.table.uniform_(-0.5, 0.5)
     nets = [net.cuda(), copy.deepcopy(net).cuda()]
     steps = [amd.trainer.FusedStep(q, q.configure_optimizers()) for q in nets]
-    steps[0].overlap_forward = True   # off by default: measured slower
+    steps[0].overlap_forward = True   # off by default: measured slower (EXPERIMENTS.md Part II 4.7)
     assert not steps[1].overlap_forward
     g = torch.Generator().manual_seed(n)
     for k in range(4):

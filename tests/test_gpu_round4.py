@@ -179,7 +179,7 @@ def test_siren_chain_products_at_extreme_scales(amd, s):
 
 
 def test_where_the_three_term_split_stops_being_exact(amd, capsys):
-    """Documents the edges (DESIGN.md 4.9) instead of leaving them to be found: the decoder's forward pass with the
+    """Documents the edges (DESIGN.md 2 and 4.4) instead of leaving them to be found: the decoder's forward pass with the
     first layer (and the biases) scaled by 2^s, s from -118 to +120, prediction at 2^s.  Asserted: f32-accurate
     (1e-5; in practice ~1e-7) for -100 <= s <= 120.  Below that the third term l ~ 2^-16 |x|, then the second,
     m ~ 2^-8 |x|, drop under the smallest NORMAL bf16 (2^-126): the product degrades towards a two-term (2^-16) and

@@ -15,8 +15,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-rdir = sys.argv[2] if len(sys.argv) > 2 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rdir = sys.argv[2] if len(sys.argv) > 2 else "r4"
 src = os.path.join(ROOT, "gpurun_out", rdir, "final")
 dst = os.path.join(ROOT, "profiles")
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # measurement batch of a round: bench lines of every workload, kernel stats, PMC traffic
 #   MRI_ROUND=r3 bash tools/gpu_final.sh [part ...]     parts: bench prof pmc (default: all)
-export MRI_ROUND=${MRI_ROUND:-r3}
+export MRI_ROUND=${MRI_ROUND:-r4}
 o=gpurun_out/$MRI_ROUND/final; mkdir -p $o
 parts=${@:-bench prof pmc}   # (pmc2: only the FETCH / WRITE passes of cfg2 and cfg5)
 run() { local name=$1 limit=$2; shift 2; timeout -k 10 "$limit" "$@" > "$o/$name.json" 2> "$o/$name.err"; local rc=$?; echo "$name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi; }

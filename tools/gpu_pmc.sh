@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/gpu_pmc.sh NAME "COUNTERS" bench-args...
 name=$1; ctrs=$2; shift 2
-out=$GRAFT_REPO_ROOT/gpurun_out/${MRI_ROUND:-r3}/pmc_$name
+out=$GRAFT_REPO_ROOT/gpurun_out/${MRI_ROUND:-r4}/pmc_$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --pmc $ctrs --output-format csv -d $out -o $name -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --psnr-steps 0 > $out/bench.out 2> $out/bench.err

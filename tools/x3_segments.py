@@ -84,7 +84,10 @@ def main():
     pw = p[:, :, :10].sum(dim=2).mean(dim=0) / tiles
     print("  per wave total:", " ".join(f"{float(v):.0f}" for v in pw))
     work = p[:, :, 0:10:2].mean(dim=0) / tiles
-    print("  work per wave, segment S6:", " ".join(f"{float(v):.0f}" for v in work[:, 4]))
+    wait = p[:, :, 1:10:2].mean(dim=0) / tiles
+    for i, nm in ((2, "S2"), (3, "S5"), (4, "S6")):
+        print(f"  {nm} per wave: work", " ".join(f"{float(v):.0f}" for v in work[:, i]), "| wait",
+              " ".join(f"{float(v):.0f}" for v in wait[:, i]))
 
 
 if __name__ == "__main__":
