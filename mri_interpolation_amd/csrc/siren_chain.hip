@@ -157,11 +157,9 @@ __device__ __forceinline__ void issue_chunk(const char* __restrict__ wsplit, int
 // layer (round 4): `fa` holds THIS chunk's fragment, already split (the image is complete when a layer starts, only
 // the weights arrive chunk by chunk); the f32 words of the NEXT chunk's fragment (`a_next`: the lane's image row at
 // that chunk's first k, + 4 lh; null for a layer's last chunk) are requested together with this chunk's weight
-// fragments and split while this chunk's MFMAs execute -- read and split in front of its own MFMAs, as until round
-// 3, the 44 vector instructions and an LDS round trip stood between every chunk barrier and the first MFMA behind
-// it: config 3 13.31 -> 12.64 ms on one box (forward 5.55 -> 5.14, backward 7.74 -> 7.45), bit-identical results.
-// (The weight fragments a chunk ahead as well -- a three-deep DMA ring, the MFMAs of a chunk finding both operands
-// in registers -- measured 13.10 against 13.32 ms: 24 more registers and a third 24 KiB buffer for less.)
+// fragments and split while this chunk's MFMAs execute.  Measured neutral against reading and splitting in front of
+// the chunk's own MFMAs (config 3 12.82 against 12.81 ms, same flags, same box; EXPERIMENTS.md corrects the first
+// claim); the weight fragments a chunk ahead as well (a three-deep DMA ring) measured slower.
 template <int NT, int H>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], x3::Frag& fa, const float* __restrict__ a_next,
                                           const char* __restrict__ wb, const int (&boff)[NT]) {
@@ -177,6 +175,19 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], x3::Frag& fa, const
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = mma6_32(fa, fb[t], acc[t]);
   if (a_next) fa = split_octets(n_lo, n_hi);
+}
+// Scheduling pattern for a region of N MFMAs with LDS reads and vector work to hide beside them: after each of the
+// first four MFMAs READS_PER LDS reads, after each of the others VALU_PER vector instructions.
+template <int N, int READS_PER, int VALU_PER, int I = 0>
+__device__ __forceinline__ void sched_interleave() {
+  if constexpr (I < N) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (I < 4)
+      __builtin_amdgcn_sched_group_barrier(0x100, READS_PER, 0);
+    else
+      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);
+    sched_interleave<N, READS_PER, VALU_PER, I + 1>();
+  }
 }
 // the first fragment of a layer (behind the barrier that completes the image)
 __device__ __forceinline__ x3::Frag first_fragment(const float* __restrict__ a_k) {
@@ -863,29 +874,73 @@ __global__ __launch_bounds__(kThreads) void siren_wgrad_kernel(const WgradArgs g
     if constexpr (kPairs % 8 == 0) {
       // a 16-deep step contracts eight of the wave's row pairs: lane half lh holds row 2 pair + lh,
       // element j of both operands = pair split + (8 s + j) RS
+      // Both operands are split a tile ahead, beside the MFMAs of the tile before (one MFMA, then a share of the
+      // reads / of the split's 44 vector instructions per fragment: a bf16 MFMA leaves the issue port free for 24 of
+      // its 32 cycles).  Split in front of their own MFMAs, as until round 4, the matrix pipe idled meanwhile
+      // (weight gradient 0.75 -> 0.64 ms per layer at config 3).
+      float raw[8];
+      auto fetch_a = [&](int s, int tj) {
 #pragma unroll
-      for (int s = 0; s < kPairs / 8; ++s) {
-        x3::Frag fz[TI];
+        for (int j = 0; j < 8; ++j) raw[j] = ap[2 * (split + (8 * s + j) * RS) * H + tj * 32];
+      };
+      float rz[TI][8];
+      auto fetch_z = [&](int s) {
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-          float v[8];
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = zp[2 * (split + (8 * s + j) * RS) * H + ti * 32];
-          fz[ti] = x3::split8(v);
-        }
-        float raw[2][8];
-        auto fetch_a = [&](int b, int tj) {
+          for (int j = 0; j < 8; ++j) rz[ti][j] = zp[2 * (split + (8 * s + j) * RS) * H + ti * 32];
+      };
+      x3::Frag fz[TI], fa, fz_keep0;
+      fetch_z(0);
+      fetch_a(0, 0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) raw[b][j] = ap[2 * (split + (8 * s + j) * RS) * H + tj * 32];
-        };
-        fetch_a(0, 0);
+      for (int ti = 0; ti < TI; ++ti) fz[ti] = x3::split8(rz[ti]);
+      fa = x3::split8(raw);
+      constexpr int kSteps = kPairs / 8, kM = 6 * TI;  // (kM MFMAs per tile: the first four carry reads, the others vector work)
+      // where the NEXT step's dz fragments are read and split: spread over the last tiles of a step when it has
+      // three or more (H = 256: read beside tile 1, split beside tiles 2 and 3), else all beside its last tile
+      constexpr bool kSpread = TJ >= 3 && TI == 2;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) {
+        const bool next_step = s + 1 < kSteps;
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
-          if (tj + 1 < TJ) fetch_a((tj + 1) & 1, tj + 1);
+          const bool last_tile = tj + 1 == TJ, more = !last_tile || next_step;
           __builtin_amdgcn_sched_barrier(0);
-          const x3::Frag fa = x3::split8(raw[tj & 1]);
+          if (!last_tile) fetch_a(s, tj + 1);
+          if (last_tile && next_step) fetch_a(s + 1, 0);
+          const bool z_read = next_step && (kSpread ? tj == TJ - 3 : last_tile);
+          if (z_read) fetch_z(s + 1);
+          x3::Frag fz_use[TI];
 #pragma unroll
-          for (int ti = 0; ti < TI; ++ti) acc[ti][tj] = mma6_32(fz[ti], fa, acc[ti][tj]);
+          for (int ti = 0; ti < TI; ++ti) fz_use[ti] = fz[ti];
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) acc[ti][tj] = mma6_32(fz_use[ti], fa, acc[ti][tj]);
+          if (more) fa = x3::split8(raw);
+          x3::Frag fz_next[TI];
+          int z_splits = 0;
+          if (next_step) {
+            if (kSpread) {
+              if (tj == TJ - 2) fz_next[0] = x3::split8(rz[0]), z_splits = 1;
+              if (tj == TJ - 1) fz_next[TI - 1] = x3::split8(rz[TI - 1]), z_splits = 1;
+            } else if (last_tile) {
+#pragma unroll
+              for (int ti = 0; ti < TI; ++ti) fz_next[ti] = x3::split8(rz[ti]);
+              z_splits = TI;
+            }
+          }
+          // (fz of this step is still in use by the tiles behind this one: the new fragments take over at the step's end)
+          if (more && !z_read && z_splits == 0) sched_interleave<kM, 2, (44 + kM - 5) / (kM - 4)>();
+          if (more && z_read && z_splits == 0) sched_interleave<kM, 2 * (1 + TI), (44 + kM - 5) / (kM - 4)>();
+          if (more && !z_read && z_splits == 1) sched_interleave<kM, 2, (88 + kM - 5) / (kM - 4)>();
+          if (more && z_read && z_splits > 0) sched_interleave<kM, 2 * (1 + TI), (44 * (1 + TI) + kM - 5) / (kM - 4)>();
+          if (kSpread) {
+            if (next_step && tj == TJ - 2) fz_keep0 = fz_next[0];
+            if (next_step && last_tile) fz[0] = fz_keep0, fz[TI - 1] = fz_next[TI - 1];
+          } else if (next_step && last_tile) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) fz[ti] = fz_next[ti];
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }

@@ -10,6 +10,8 @@ PY
 }
 run() { name=$1; lib=$2; shift 2; MRI_LIB=$lib timeout -k 10 300 python bench.py --workload cfg3 --no-cpu-baseline --psnr-steps 0 "$@" > $o/$name.json 2> $o/$name.err; rc=$?; [ $rc -ne 0 ] && { echo "$name rc=$rc"; tail -3 $o/$name.err; }; [ $rc -eq 124 -o $rc -eq 137 ] && exit 1; line $o/$name.json; }
 run new_a mri_interpolation_amd/libmri_inr.so
-run old_a tools/libmri_old.so
+run head_a tools/libmri_head.so
+run r3_a tools/libmri_r3siren.so
 run new_b mri_interpolation_amd/libmri_inr.so
-run old_b tools/libmri_old.so
+run head_b tools/libmri_head.so
+run r3_b tools/libmri_r3siren.so
