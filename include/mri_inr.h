@@ -70,7 +70,9 @@ const char* mri_last_error(void);
 /* Speed-only tuning knobs ("xcd_affinity" 0/1, "bwd_lds_max_parts" n, "bwd_blocks_per_level" n,
  * "bwd_dense_max_parts" n, "bwd_dense_blocks" n, "bwd_fuse_dense" 0/1, "fwd_pair" 0/1,
  * "mlp_stagger" 0..8, "mlp_x3" 0/1/2: which kernel serves the decoder -- 1 (default) the bf16-pipe
- * kernel with exact three-term operands, 2 its four-wave form (128-wide), 0 the f32-MFMA kernels);
+ * kernel with exact three-term operands, 2 its four-wave form (128-wide), 0 the f32-MFMA kernels;
+ * "siren_rows" 0/1: SirenNet of width 256 -- 1 (default) the chain kernels that keep a wave's rows in
+ * registers across the layers (csrc/siren_rows.hip), 0 the LDS-image kernels of every other width);
  * results stay within fp32 summation-order noise.
  * ONE option trades accuracy, for grids with two features per level: "bwd_records" 0 (default) / 1,
  * the gradient records of mri_hashgrid_backward* (see there).  0: every contribution w * g is the f32

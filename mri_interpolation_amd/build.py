@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libmri_inr.so")
 SOURCES = ["hashgrid.hip", "hashgrid_bwd.hip", "linear.hip", "linear_small.hip", "mlp_fused.hip", "mlp_x3.hip", "train_ops.hip",
-           "frequency.hip", "siren_chain.hip", "fused_step.hip"]
+           "frequency.hip", "siren_chain.hip", "siren_rows.hip", "fused_step.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          # the reference multiplies and adds separately (encoding.py:111-128, torch Adam);
          # keep those roundings instead of contracting to fma
@@ -29,7 +29,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
 # into v_pk_add_f32, the slower form beside bf16 MFMAs (MI355X_MICROARCH.md, packed f32 VALU):
 # config-3 step 13.25 -> 12.58 ms without it (the explicitly packed sincos stays: 12.72 unpacked).
 # The decoder kernels measured the same either way.
-EXTRA_FLAGS = {"siren_chain.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"siren_chain.hip": ["-fno-slp-vectorize"], "siren_rows.hip": ["-fno-slp-vectorize",
+                                                                                     # the order fixed before register allocation (sched_group_barrier)
+                                                                                     # is the one wanted: the post-RA scheduler re-solves the groups with
+                                                                                     # the allocator's copies in them and undoes the interleave
+                                                                                     "-mllvm", "-enable-post-misched=false"]}
 
 
 def _hipcc():

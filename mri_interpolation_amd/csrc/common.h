@@ -51,6 +51,7 @@ struct Options {
   // (the reference's precision: f32 products, here even summed exactly); 1 = packed 8-byte records, every
   // product rounded to 18-21 significant bits before the exact sum (13 us faster at config 4, NOT f32).
   int bwd_records = 0;
+  int siren_rows = 1;             // SirenNet H = 256: the chain kernels that keep a wave's rows in registers (siren_rows.hip)
 };
 Options& options();
 

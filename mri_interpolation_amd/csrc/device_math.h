@@ -31,23 +31,11 @@ __device__ __forceinline__ void sincos_fast(float u, float* s_out, float* c_out)
   *c_out = ((q + 1) & 2) ? -c1 : c1;
 }
 
-// Two arguments at once on the packed f32 FMA / multiply (v_pk_fma_f32, v_pk_mul_f32: two elements
-// of f32 per instruction slot): the reduction and both polynomials are FMA chains, only the
-// rounding, the quadrant logic and the range check stay per element.  Same arithmetic as
-// sincos_fast, operation for operation.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void sincos_fast2(float u0, float u1, float* s0, float* c0, float* s1,
-                                             float* c1) {
-#ifdef MRI_SCALAR_SINCOS  // A/B builds: beside bf16 MFMAs packed f32 VALU can be the slower form
-  sincos_fast(u0, s0, c0);
-  sincos_fast(u1, s1, c1);
-  return;
-#endif
-  if (fabsf(u0) > 8192.0f || fabsf(u1) > 8192.0f) {
-    sincos_fast(u0, s0, c0);
-    sincos_fast(u1, s1, c1);
-    return;
-  }
+// The branch-free body of sincos_fast2 (|u| <= 8192 is the CALLER's business: siren_rows.hip interleaves this
+// with matrix instructions, checks the range per tile and repairs out-of-range values on a cold path).
+__device__ __forceinline__ void sincos_fast2_core(float u0, float u1, float* s0, float* c0, float* s1,
+                                                  float* c1) {
   const f32x2 u = {u0, u1};
   const f32x2 t = u * 0.636619772367581343f;
   const f32x2 k = {rintf(t.x), rintf(t.y)};
@@ -75,6 +63,25 @@ __device__ __forceinline__ void sincos_fast2(float u0, float u1, float* s0, floa
     *s1 = (q & 2) ? -a : a;
     *c1 = ((q + 1) & 2) ? -b : b;
   }
+}
+
+// Two arguments at once on the packed f32 FMA / multiply (v_pk_fma_f32, v_pk_mul_f32: two elements
+// of f32 per instruction slot): the reduction and both polynomials are FMA chains, only the
+// rounding, the quadrant logic and the range check stay per element.  Same arithmetic as
+// sincos_fast, operation for operation.
+__device__ __forceinline__ void sincos_fast2(float u0, float u1, float* s0, float* c0, float* s1,
+                                             float* c1) {
+#ifdef MRI_SCALAR_SINCOS  // A/B builds: beside bf16 MFMAs packed f32 VALU can be the slower form
+  sincos_fast(u0, s0, c0);
+  sincos_fast(u1, s1, c1);
+  return;
+#endif
+  if (fabsf(u0) > 8192.0f || fabsf(u1) > 8192.0f) {
+    sincos_fast(u0, s0, c0);
+    sincos_fast(u1, s1, c1);
+    return;
+  }
+  sincos_fast2_core(u0, u1, s0, c0, s1, c1);
 }
 
 __device__ __forceinline__ float gelu_f(float z) {

@@ -27,6 +27,7 @@
 #include "bf16x3.h"
 #include "common.h"
 #include "device_math.h"
+#include "siren_chain.h"
 
 // The H x H products run on the bf16 matrix pipe, f32-accurate (bf16x3.h): every operand is split
 // exactly into three bf16 terms and a 16-deep step is six v_mfma_f32_32x32x16_bf16 -- 6/16 of the f32
@@ -48,10 +49,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 512;  // 8 waves
-constexpr int kKc = 16;        // contraction depth of a weight chunk: one bf16 MFMA step
 constexpr int kWr = 32;        // batch rows per chunk of the weight-gradient kernel
-constexpr int kMaxSine = MRI_SIREN_MAX_LAYERS;  // sine layers, the first one included
-constexpr int kMaxIn = 8;
 
 // Geometry for hidden width H: a wave owns a 32 x CT tile of the (rows x H) layer output, the 8
 // waves are RB row blocks x CB column blocks, so narrower networks take taller tiles and every
@@ -71,28 +69,6 @@ struct Shape {
   static constexpr int drip = 16 / chunks;          // accumulator registers dripped per chunk
   static_assert(H == 32 || H == 64 || H == 128 || H == 256, "hidden width");
 };
-
-struct ChainArgs {
-  const float* x;                   // (n, dim_in) row-major
-  int64_t n;
-  int dim_in, n_sine;
-  const float* w[kMaxSine + 1];     // [0] (H, dim_in); [1 .. n_sine-1] (H, H); [n_sine] (1, H)
-  const float* b[kMaxSine + 1];
-  float w0_first, w0;
-  float* act[kMaxSine];             // (n, H) per sine layer, or null (inference)
-  float* deriv[kMaxSine];
-  float* y;                         // (n)
-  // loss mode (MODE 2): the head's backward runs in the forward kernel's tail, where the last sine
-  // layer's output and derivative are still in registers
-  const float* target;              // (n)
-  float grad_scale, inv_n;          // 2 / (n_total divisor), 1 / n_total
-  float* dz_last;                   // (n, H): dLoss / d(pre-activation of the last sine layer)
-  float* partial;                   // [gridDim.x][fwd_slab_floats]
-  const char* wsplit;               // split W of layers 1 .. n_sine-1 (split_matrix_bytes each)
-};
-
-// loss-mode slab: dW_head [H] | db_last [H] | db_head, loss (padded to 4)
-__host__ __device__ inline int fwd_slab_floats(int hidden) { return 2 * hidden + 4; }
 
 template <class S>
 struct FwdSmem {
@@ -125,13 +101,6 @@ __device__ __forceinline__ x3::Frag split_octets(const float4& lo, const float4&
   const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return x3::split8(v);
 }
-
-// Split weights (siren_split_weights_kernel): per H x H matrix, chunk kc = contraction indices
-// [16 kc, 16 kc + 16), term planes h | m | l of [H rows][2 slots][8 bf16]; slot q of row n holds
-// contraction indices 16 kc + 4 q + e and 16 kc + 8 + 4 q + e (e = 0..3): the eight positions lane
-// half q of a 32x32x16 MFMA contracts when the other operand is read from the f32 image as two
-// 16-byte fragments at k = 4 q and 8 + 4 q.  A chunk is contiguous: 3 x H x 32 bytes.
-__host__ __device__ inline int64_t split_matrix_bytes(int H) { return (int64_t)(H / kKc) * 3 * H * 32; }
 
 // Queue the LDS-DMA of chunk kc of one split matrix into `dst`: 16-byte slots, lane = slot.  The
 // slot a lane FETCHES is its LDS slot with the half bit XORed by bit 3 of the row, the involution
@@ -493,25 +462,6 @@ __global__ __launch_bounds__(kThreads) void siren_forward_kernel(const ChainArgs
 // dz_l (l >= 1) leaves for HBM once: siren_wgrad_kernel contracts it with a_{l-1} over the batch.
 // Partial sums (biases, head, first layer) leave through one slab per workgroup, summed in a
 // fixed order by siren_bwd_reduce_kernel (bitwise reproducible, no float atomics).
-struct BwdArgs {
-  const float* x;                  // (n, dim_in)
-  const float* dy;                 // (n): dLoss / dy
-  int64_t n;
-  int dim_in, n_sine;
-  const float* w[kMaxSine + 1];    // as ChainArgs
-  const float* act_last;           // (n, H): output of the last sine layer
-  const float* deriv[kMaxSine];    // (n, H) per sine layer: w0 cos(.)
-  float* dz[kMaxSine];             // (n, H) for sine layers 1 .. n_sine-1 ([0] unused)
-  float* partial;                  // [gridDim.x][bwd_slab_floats]
-  const char* wtsplit;             // split W^T of layers 1 .. n_sine-1 (split_matrix_bytes each)
-  int head_done;                   // dz[n_sine-1] is an INPUT (the forward kernel's loss mode wrote it)
-};
-
-// slab: dW_head [H] | db_head [1] (padded to 4) | db_l [n_sine][H] | dW_first [H][kMaxIn]
-__host__ __device__ inline int bwd_slab_floats(int hidden, int n_sine) {
-  return hidden + 4 + n_sine * hidden + hidden * kMaxIn;
-}
-
 template <class S>
 struct BwdSmem {
   char wbuf[2][S::chunk_bytes] __attribute__((aligned(16)));  // chunks of the split W^T: term planes [k][2 slots]
@@ -1089,6 +1039,7 @@ int launch_wgrad(const WgradArgs& g, float* d_weight, hipStream_t st) {
 }
 
 int forward_any(int hidden, const ChainArgs& a, int mode, hipStream_t st) {
+  if (options().siren_rows && rows_supported(hidden, a.n_sine)) return forward_rows(a, mode, st);
   switch (hidden) {
     case 32: return launch_forward<32>(a, mode, st);
     case 64: return launch_forward<64>(a, mode, st);
@@ -1236,7 +1187,8 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   if (int rc = split_weights(weight, n_sine_layers, hidden, false, wsplit, st)) return rc;
   if (int rc = forward_any(hidden, a, 2, st)) return rc;
   FwdReduceArgs r{};
-  r.partial = a.partial, r.slabs = blocks, r.hidden = hidden;
+  r.partial = a.partial, r.hidden = hidden;
+  r.slabs = options().siren_rows && rows_supported(hidden, n_sine_layers) ? rows_blocks(n) : blocks;
   r.d_w_head = d_w_head, r.d_b_head = d_b_head, r.d_b_last = d_b_last, r.loss_out = loss_out;
   hipLaunchKernelGGL(siren_fwd_reduce_kernel, dim3((unsigned)ceil_div(fwd_slab_floats(hidden), 256)),
                      dim3(256), 0, st, r);

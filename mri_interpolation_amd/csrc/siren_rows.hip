@@ -1,0 +1,673 @@
+// Fused SIREN chain for H = 256 with the activations of a wave's rows IN REGISTERS across all layers (round 4).
+//
+// Same contract as siren_chain.hip (reference models.py:153-156 SirenLayer.forward, :230-233 SirenNet.forward:
+// `F.linear` + `sin(w0 .)` per layer, then the linear head), same arguments, same split-weight workspace.  What
+// changes is who owns what.  siren_chain.hip keeps a 64-row tile's activations as an f32 image in LDS: eight waves
+// share it, every wave re-reads and re-splits the image fragments the other column blocks also read, every
+// 16-deep weight chunk is fenced by a workgroup barrier (64 per tile), the sincos epilogue of a layer runs with the
+// matrix pipe idle, and the 66 KB image leaves room for two 24 KB weight chunks only -- the whole H x H matrix is
+// streamed from L2 once per 64 rows.  Here:
+//
+//   * the product is computed TRANSPOSED, Z^T = W A^T: the weights are the MFMA's A operand (32 output features
+//     per tile), a wave's 32 batch rows are the N dimension.  The 32x32 accumulator then holds, per lane, one batch
+//     row (lane & 31) and the features (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the tile -- which is exactly the
+//     B-operand layout of the NEXT layer's products over the contraction order the split weights already use
+//     (siren_chain.h: slot q of a row holds k = 16 kc + 4 q + e and 16 kc + 8 + 4 q + e).  A layer's output becomes
+//     the next layer's operand with no exchange at all: every activation is split into its three bf16 terms ONCE,
+//     by the lane that computed it, and is never written to LDS;
+//   * one workgroup = 4 waves, one per SIMD, 128 rows; a wave owns its 32 rows through the whole chain (up to 512
+//     registers per lane: 192 for the layer's split input, 128 for its f32 output, 32 for two accumulator tiles);
+//   * LDS holds nothing but a ring of weight chunks (4 x 24 KB; a chunk = the 32 features of one output tile x
+//     128 contraction indices x three terms) filled by LDS-DMA three chunks ahead; the matrix is streamed once per
+//     128 rows (half the L2 traffic per row), one workgroup barrier per chunk = per 48 MFMAs of a wave, placed
+//     two k-steps before the chunk's end so that the next chunk's first fragments are requested early;
+//   * the sincos epilogue of output tile i runs beside the MFMAs of tile i + 1 IN THE SAME WAVE: the order
+//     (one MFMA, a few vector instructions, ...) is fixed by __builtin_amdgcn_sched_group_barrier.  The branch
+//     of sincos_fast2 (|u| > 8192 -> library sincosf) would cut those scheduling regions: the interleaved code is
+//     branch-free, the range is checked once per tile and out-of-range values are repaired on a cold path.
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "bf16x3.h"
+#include "common.h"
+#include "device_math.h"
+#include "siren_chain.h"
+
+namespace mri {
+namespace {
+namespace rr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kH = 256;
+constexpr int kThreadsR = 256;                   // 4 waves, one per SIMD
+constexpr int kRows = 128;                       // rows of a group: 32 per wave
+constexpr int kTiles = kH / 32;                  // output tiles of 32 features
+constexpr int kSteps = kH / kKc;                 // 16-deep k-steps per layer
+constexpr int kChunkSteps = 8;                   // k-steps per weight chunk: a chunk = (tile, half of K)
+constexpr int kChunksPerLayer = kTiles * 2;
+constexpr int kPiece = 32 * 32;                  // bytes of one term plane of one k-step of one tile
+constexpr int kChunk = kChunkSteps * 3 * kPiece; // 24,576
+constexpr int kRing = 4;
+constexpr int kStgLd = 36;                        // floats per staged row: 144 bytes, conflict-free 16-byte writes
+constexpr int kPlane = kH * 32;                  // one term plane of one k-step of the whole matrix (siren_chain.h)
+constexpr int kStepBytes = 3 * kPlane;           // one k-step of the whole matrix: 24,576
+
+// The small arrays first: their addresses then fit the 16-bit offset field of the DS instructions (beyond 64 KB hipcc
+// keeps one address register per access, hoists hundreds of them out of the loops and spills them).
+struct Smem {
+  float bias[kMaxSine][kH] __attribute__((aligned(16)));
+  float w_first[kH][kMaxIn];
+  float w_last[kH];
+  // Per wave: a tile's a and w0 cos on their way to HBM, [array][row][32 features + pad].  A lane owns a ROW (1 KB apart
+  // in HBM): stored from registers, every 16-byte piece of a store instruction lands in another row (~180 cycles per
+  // instruction measured).  Through this image the pieces go out as the rows lie: 4 lanes per 64-byte half row.  The cold
+  // path (arguments beyond the fast sincos' range) borrows the same bytes as [value][lane].
+  float stg[4][2][32 * kStgLd];
+  char ring[kRing][kChunk] __attribute__((aligned(16)));
+};
+
+__device__ __forceinline__ f32x16 mfma(const x3::u32x4& a, const x3::u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3::bf16x8, a),
+                                                 __builtin_bit_cast(x3::bf16x8, b), c, 0, 0, 0);
+}
+// acc += W_frag (32 features x 16 k) * act_frag (16 k x 32 rows): the six products of siren_chain.hip's mma6_32
+// (activation term x weight term: l h, h l, m m, m h, h m, h h), smallest first
+__device__ __forceinline__ f32x16 kstep(const x3::Frag& w, const x3::Frag& v, f32x16 c) {
+  c = mfma(w.h, v.l, c);
+  c = mfma(w.l, v.h, c);
+  c = mfma(w.m, v.m, c);
+  c = mfma(w.h, v.m, c);
+  c = mfma(w.m, v.h, c);
+  c = mfma(w.h, v.h, c);
+  return c;
+}
+
+// Queue this wave's share (6 of the 24 one-KiB pieces) of chunk (tile, half) of one split matrix: piece pc =
+// k-step pc / 3 of the half, term plane pc % 3; lane = 16-byte slot, fetched with the half bit XORed by bit 3 of
+// the row (the involution the fragment reads undo, as siren_chain.hip's issue_chunk).
+__device__ __forceinline__ void issue(const char* __restrict__ mat, int tile, int half, char* dst, int wave, int lane) {
+  const char* src = mat + (int64_t)(kChunkSteps * half) * kStepBytes + tile * kPiece + 16 * (lane ^ ((lane >> 4) & 1));
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pc = wave + 4 * j, ksl = pc / 3, p = pc - 3 * ksl;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ksl * kStepBytes + p * kPlane),
+                                     (__attribute__((address_space(3))) void*)(dst + pc * kPiece), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ x3::Frag read_wfrag(const char* __restrict__ p) {
+  x3::Frag f;
+  f.h = *reinterpret_cast<const x3::u32x4*>(p);
+  f.m = *reinterpret_cast<const x3::u32x4*>(p + kPiece);
+  f.l = *reinterpret_cast<const x3::u32x4*>(p + 2 * kPiece);
+  return f;
+}
+
+// one MFMA, then `V` vector instructions, six times; then the three fragment reads of a k-step
+template <int V>
+__device__ __forceinline__ void sched_kstep() {
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+}
+
+// Loops whose index must be a compile-time constant (register arrays, scheduling fences): `#pragma unroll` is a
+// request the optimizer may decline (it did, and indexed the register file dynamically).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Sum each of 16 registers over the 16 lanes that share (lane >> 4): a halving butterfly -- per step a lane keeps one
+// register of a pair and sends the other to its partner; lane (lane & 15) = r ends up with the sum of register r.
+__device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
+  float a8[8], a4[4], a2[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool up = (lane & 1) != 0;
+    a8[j] = (up ? v[2 * j + 1] : v[2 * j]) + __shfl_xor(up ? v[2 * j] : v[2 * j + 1], 1, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool up = (lane & 2) != 0;
+    a4[j] = (up ? a8[2 * j + 1] : a8[2 * j]) + __shfl_xor(up ? a8[2 * j] : a8[2 * j + 1], 2, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool up = (lane & 4) != 0;
+    a2[j] = (up ? a4[2 * j + 1] : a4[2 * j]) + __shfl_xor(up ? a4[2 * j] : a4[2 * j + 1], 4, 64);
+  }
+  const bool up = (lane & 8) != 0;
+  return (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 8, 64);
+}
+
+// Cold path: sin / cos of 32 arguments per lane staged in LDS, by the library routine.
+__device__ __attribute__((noinline)) void repair_values(float* fix, int count) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int r = 0; r < count; ++r) {
+    float s, c;
+    sincosf(fix[r * 64 + lane], &s, &c);
+    fix[r * 64 + lane] = s;
+    fix[(16 + r) * 64 + lane] = c;
+  }
+}
+
+// Phase timing for tools/rows_phases.py (a tools-only build with -DSIREN_PROFILE; the shipped library compiles these
+// to nothing): shader-clock cycles per phase, per wave.
+#ifdef SIREN_PROFILE
+__device__ long long* g_rows_profile = nullptr;
+#define RP_BEGIN long long rp_t = clock64(); long long rp_acc[8] = {};
+#define RP_MARK(i) { const long long rp_n = clock64(); rp_acc[i] += rp_n - rp_t; rp_t = rp_n; }
+#define RP_END                                                                          \
+  if (g_rows_profile && (threadIdx.x & 63) == 0) {                                      \
+    long long* dst = g_rows_profile + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+    for (int q = 0; q < 8; ++q) dst[q] = rp_acc[q];                                     \
+  }
+#else
+#define RP_BEGIN
+#define RP_MARK(i)
+#define RP_END
+#endif
+
+// MODE 0: inference; 1: training (a and w0 cos of every layer leave for HBM); 2: training with the loss (siren_chain.hip's
+// MODE 2: MSE against `target` and the head's backward in the group's tail; the last sine layer's a never leaves, its
+// w0 cos waits in the dz_last buffer until the row's dLoss/dy is known and is replaced by dz there)
+template <int MODE>
+__global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const ChainArgs a) {
+  __shared__ Smem sm;
+  constexpr bool STORE = MODE >= 1, LOSS = MODE == 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n_mm = a.n_sine - 1;  // H x H layers (>= 1)
+
+  for (int l = 0; l < a.n_sine; ++l)
+    for (int e = tid; e < kH; e += kThreadsR) sm.bias[l][e] = a.b[l][e];
+  for (int e = tid; e < kH; e += kThreadsR) sm.w_last[e] = a.w[a.n_sine][e];
+  for (int e = tid; e < kH * kMaxIn; e += kThreadsR) {
+    const int f = e / kMaxIn, d = e % kMaxIn;
+    sm.w_first[f][d] = d < a.dim_in ? a.w[0][f * a.dim_in + d] : 0.f;
+  }
+  const float b_last = a.b[a.n_sine][0];
+  const int64_t groups = (a.n + kRows - 1) / kRows;
+  // this lane's slot inside a piece, per ring slot: four opaque bases, every fragment read a 16-bit offset from one
+  // (opaque OFFSETS, not pointers: a laundered pointer loses its LDS address space and the reads become flat loads)
+  int wslot[kRing];
+#pragma unroll
+  for (int q = 0; q < kRing; ++q) {
+    wslot[q] = q * kChunk + 32 * l31 + 16 * (lh ^ ((l31 >> 3) & 1));
+    asm volatile("" : "+v"(wslot[q]));
+  }
+  const char* const ring0 = &sm.ring[0][0];
+  const int feat0 = 4 * lh;  // feature of accumulator register r of tile i: 32 i + (r & 3) + 8 (r >> 2) + feat0
+
+  // the chunk stream: chunks 0, 1, 2 of the first group
+  if ((int64_t)blockIdx.x < groups) {
+    issue(a.wsplit, 0, 0, sm.ring[0], wave, lane);
+    issue(a.wsplit, 0, 1, sm.ring[1], wave, lane);
+    issue(a.wsplit, 1, 0, sm.ring[2], wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // parameters and chunk 0 .. 2 are in LDS
+
+  float g_wh[4] = {0.f, 0.f, 0.f, 0.f}, g_bl[4] = {0.f, 0.f, 0.f, 0.f}, g_bhead = 0.f, g_loss = 0.f;  // loss mode: running sums of this lane
+  // (parked in accumulation registers between the groups' tails: the tile loop has no vector register to spare)
+  auto park = [&]() {
+    if constexpr (LOSS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(g_wh[j]), "+a"(g_bl[j]));
+      asm volatile("" : "+a"(g_bhead), "+a"(g_loss));
+    }
+  };
+  park();
+  RP_BEGIN
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    // rows beyond n repeat row n - 1: the same values to the same addresses, no exec-masked store (a divergent branch
+    // would cut the scheduling regions below)
+    const int64_t row = std::min<int64_t>(g * kRows + 32 * wave + l31, a.n - 1);
+    float out[kTiles][16];  // the layer's output, accumulator layout: the next layer's operand before its split
+    // staging (STORE): this lane writes quad q of its row at wr + 8 q, reads piece (lane & 3) of rows (lane >> 2) + 16 j
+    float* const stg_w = &sm.stg[wave][0][0];
+    const int wr = l31 * kStgLd + feat0, rd = (lane >> 2) * kStgLd + 4 * (lane & 3);
+    int64_t goff[2];  // element offsets of those two rows' pieces in an (n, H) array
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      goff[j] = std::min<int64_t>(g * kRows + 32 * wave + (lane >> 2) + 16 * j, a.n - 1) * kH + 4 * (lane & 3);
+    auto stage = [&](int arr, int q, const f32x4& v) { *reinterpret_cast<f32x4*>(stg_w + arr * 32 * kStgLd + wr + 8 * q) = v; };
+    auto unstage = [&](int arr, int h, f32x4 (&v)[2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v[j] = *reinterpret_cast<const f32x4*>(stg_w + arr * 32 * kStgLd + rd + 16 * h + 16 * j * kStgLd);
+    };
+    auto put = [&](float* base, int tile, int h, const f32x4 (&v)[2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(base + goff[j] + 32 * tile + 16 * h) = v[j];
+    };
+
+    // ---- first layer on the VALU (K = dim_in) -----------------------------------------------------------
+    {
+      float xv[kMaxIn];
+#pragma unroll
+      for (int d = 0; d < kMaxIn; ++d) xv[d] = d < a.dim_in ? a.x[row * a.dim_in + d] : 0.f;
+      const bool wide = a.dim_in > 4;
+#pragma unroll
+      for (int i = 0; i < kTiles; ++i) {
+        float u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(&sm.w_first[32 * i + (r & 3) + 8 * (r >> 2) + feat0][0]);
+          float z = 0.f;
+          z += xv[0] * wa.x, z += xv[1] * wa.y, z += xv[2] * wa.z, z += xv[3] * wa.w;
+          u[r] = z;
+        }
+        if (wide) {  // dim_in > 4 (wave-uniform): the sums go on in the same order
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(&sm.w_first[32 * i + (r & 3) + 8 * (r >> 2) + feat0][4]);
+            float z = u[r];
+            z += xv[4] * wb.x, z += xv[5] * wb.y, z += xv[6] * wb.z, z += xv[7] * wb.w;
+            u[r] = z;
+          }
+        }
+        float amax = 0.f, c[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          u[r] = a.w0_first * (u[r] + sm.bias[0][32 * i + (r & 3) + 8 * (r >> 2) + feat0]);
+          amax = fmaxf(amax, fabsf(u[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) sincos_fast2_core(u[r], u[r + 1], &out[i][r], &c[r], &out[i][r + 1], &c[r + 1]);
+        if (__builtin_amdgcn_ballot_w64(!(amax <= 8192.0f)) != 0) {  // wave-uniform, cold
+          float* fix = &sm.stg[wave][0][0];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fix[r * 64 + lane] = u[r];
+          repair_values(fix, 16);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[i][r] = fix[r * 64 + lane], c[r] = fix[(16 + r) * 64 + lane];
+        }
+        if (STORE) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            stage(0, q, f32x4{out[i][4 * q], out[i][4 * q + 1], out[i][4 * q + 2], out[i][4 * q + 3]});
+            stage(1, q, f32x4{a.w0_first * c[4 * q], a.w0_first * c[4 * q + 1], a.w0_first * c[4 * q + 2], a.w0_first * c[4 * q + 3]});
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 va[2], vd[2];
+            unstage(0, h, va), unstage(1, h, vd);
+            put(a.act[0], i, h, va), put(a.deriv[0], i, h, vd);
+          }
+        }
+      }
+    }
+
+    RP_MARK(0)  // first layer
+    // ---- H x H layers ------------------------------------------------------------------------------------
+    for (int l = 1; l <= n_mm; ++l) {
+      const char* mat = a.wsplit + (int64_t)(l - 1) * split_matrix_bytes(kH);
+      const char* mat_next = l < n_mm ? mat + split_matrix_bytes(kH) : a.wsplit;
+      // The last sine layer of the loss mode: a stays on chip, w0 cos waits in dz_last.  Its a is stored all the same -- into
+      // dz_last, a slice ahead of the w0 cos that overwrites it: a wave-uniform branch around those stores would cut the
+      // regions below into blocks, and the compiler then sinks the range check's running maximum behind them, keeping
+      // (spilling) every slice's arguments until the tile's end.
+      const bool keep_a = LOSS && l == n_mm;
+      float* gd = STORE ? (keep_a ? a.dz_last : a.deriv[l]) : nullptr;
+      float* ga = STORE ? (keep_a ? a.dz_last : a.act[l]) : nullptr;
+      const float w0 = a.w0;
+
+      // the layer's operand: k-step ks contracts features 16 ks + 4 lh + (j & 3) + 8 (j >> 2) = registers 8 (ks & 1) + j of tile ks / 2
+      x3::Frag cur[kSteps];
+#pragma unroll
+      for (int ks = 0; ks < kSteps; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = out[ks >> 1][8 * (ks & 1) + j];
+        cur[ks] = x3::split8(v);
+        // pinned to the accumulation registers (the MFMA reads its B operand there): left to itself the allocator keeps
+        // these 192 registers as VGPRs, spills them to AGPRs and copies every fragment back in front of its MFMAs
+        asm("" : "+a"(cur[ks].h), "+a"(cur[ks].m), "+a"(cur[ks].l));
+      }
+
+      RP_MARK(1)  // the operand's split
+      // One accumulator per tile (two tiles in flight: the epilogue of tile i - 1 reads its accumulator while tile i fills
+      // the other); a single chain of this MFMA issues at its full rate (MI355X_MICROARCH.md; two interleaved chains
+      // measured the same).  A region = the 12 MFMAs of two k-steps.  WHEN the fragments are requested matters: hipcc
+      // turns every LDS wait into lgkmcnt(0) while an LDS-DMA is in flight (always, here), so a request issued just in
+      // front of a wait is paid in full by the MFMA behind that wait.  The second k-step's fragment is requested behind
+      // the region's first MFMA (six MFMAs before its use), the NEXT region's first fragment behind the seventh: both
+      // waits (in front of MFMA 1 and MFMA 7) then find only requests that are five MFMAs old.
+      f32x16 acc[2];
+      x3::Frag wf[2];
+      wf[0] = read_wfrag(ring0 + wslot[0]);  // chunk 0 of the layer sits in ring slot 0 (16 chunks per layer)
+      float bnx = 0.f, bny = 0.f;  // the next slice's bias pair, requested half a region ahead
+      float amax = 0.f;  // largest |argument| of the tile whose epilogue is running
+      float smax = 0.f;  // largest |sine| (never above 1: see the epilogue)
+      float dd[4];       // w0 cos of the quad being assembled
+
+      static_for<kTiles + 1>([&](auto i_c) {  // iteration i: MFMAs of tile i, epilogue of tile i - 1
+        constexpr int i = decltype(i_c)::value;
+        static_for<2>([&](auto hf_c) {
+          constexpr int hf = decltype(hf_c)::value;
+          constexpr int p = 2 * i + hf;  // chunk of the layer
+          static_for<4>([&](auto rg_c) {
+            constexpr int rg = decltype(rg_c)::value;
+            constexpr int ks = kChunkSteps * hf + 2 * rg;  // this region's k-steps: ks (accA), ks + 1 (accB)
+            if constexpr (i < kTiles && rg == 3) {
+              // ---- chunk p + 1 has landed for everyone, chunk p - 1's slot is free (chunk p + 3 goes there, below) ----
+              __builtin_amdgcn_sched_barrier(0);
+              RP_MARK(2)  // MFMAs + interleaved epilogue
+              asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // at most chunk p + 2's six pieces behind it
+              __builtin_amdgcn_s_barrier();
+              RP_MARK(3)  // chunk wait + barrier
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i < kTiles && rg == 3) {
+              // Always queued, also behind the kernel's last chunk (the first layer's chunks again, never read): the
+              // stream has no tail, every wait above is the same count, no branch cuts this region.
+              constexpr int q = p + 3;
+              issue(q < kChunksPerLayer ? mat : mat_next, (q & (kChunksPerLayer - 1)) >> 1, q & 1, sm.ring[q & 3], wave, lane);
+            }
+            // ---- the region: the 12 MFMAs of k-steps ks and ks + 1, and in the gaps between them the epilogue slice of
+            // tile i - 1 (accumulator registers 2 pj, 2 pj + 1: bias, w0, the sincos of sincos_fast2_core operation for
+            // operation, the derivative, the stores).  The order is written out and fenced gap by gap: a
+            // sched_group_barrier pipeline was dropped by the scheduler whenever it judged the interleaved order's
+            // register pressure too high (back to all-VALU-then-all-MFMA).  Everything is SCALAR f32: one v_pk_fma_f32
+            // beside MFMAs costs 22 cycles more than two v_fma_f32 (MI355X_MICROARCH.md), and a gap hides five to six
+            // 4-cycle instructions -- 54 (inference) / 68 (training) of them per slice over 12 gaps.
+            constexpr int ti = i > 0 ? i - 1 : 0, pj = 4 * hf + rg, r0 = 2 * pj;
+            constexpr bool mm = i < kTiles, ep = i > 0;
+            constexpr bool first = hf == 0 && rg == 0;
+            constexpr bool next_chunk = rg == 3;
+            constexpr bool have_next = mm && !(next_chunk && p + 1 >= kChunksPerLayer);  // the next layer requests its own
+            // the next region's first fragment: k-step 2 rg + 2 of this chunk, or 0 of the next (synced above)
+            const char* nA = ring0 + wslot[(p + (next_chunk ? 1 : 0)) & 3] + 3 * kPiece * (next_chunk ? 0 : 2 * rg + 2);
+            const char* tB = ring0 + wslot[p & 3] + 3 * kPiece * (2 * rg + 1);  // this region's second fragment
+            float bx = 0.f, by = 0.f, ux = 0.f, uy = 0.f, kx = 0.f, ky = 0.f, rx = 0.f, ry = 0.f, zx = 0.f, zy = 0.f;
+            float psx = 0.f, psy = 0.f, pcx = 0.f, pcy = 0.f, hx = 0.f, hy = 0.f, snx = 0.f, sny = 0.f, csx = 0.f, csy = 0.f;
+            float ax = 0.f, ay = 0.f, sx = 0.f, sy = 0.f, cx = 0.f, cy = 0.f;
+            int qx = 0, qy = 0;
+            f32x4 fl[2];  // a half row on its way out
+            bool ex = false, ey = false, nx = false, ny = false;  // quadrant bits 0 / 1 clear
+            constexpr int kOps = STORE ? 31 : 27;
+            auto op = [&](auto n_c) {
+              constexpr int n = decltype(n_c)::value;
+              if constexpr (n == 0) ux = acc[ti & 1][r0], uy = acc[ti & 1][r0 + 1];
+              if constexpr (n == 1) ux += bx, uy += by;
+              if constexpr (n == 2) ux *= w0, uy *= w0;
+              if constexpr (n == 3) amax = fmaxf(amax, fmaxf(fabsf(ux), fabsf(uy)));
+              if constexpr (n == 4) kx = ux * 0.636619772367581343f, ky = uy * 0.636619772367581343f;
+              if constexpr (n == 5) kx = rintf(kx), ky = rintf(ky);
+              if constexpr (n == 6) qx = (int)kx, qy = (int)ky;
+              if constexpr (n == 7) rx = __builtin_fmaf(kx, -1.57079625129699707031e+00f, ux), ry = __builtin_fmaf(ky, -1.57079625129699707031e+00f, uy);
+              if constexpr (n == 8) rx = __builtin_fmaf(kx, -7.54978941586159635335e-08f, rx), ry = __builtin_fmaf(ky, -7.54978941586159635335e-08f, ry);
+              if constexpr (n == 9) rx = __builtin_fmaf(kx, -5.39030252995776476554e-15f, rx), ry = __builtin_fmaf(ky, -5.39030252995776476554e-15f, ry);
+              if constexpr (n == 10) zx = rx * rx, zy = ry * ry;
+              if constexpr (n == 11) psx = __builtin_fmaf(-1.9515295891e-4f, zx, 8.3321608736e-3f), psy = __builtin_fmaf(-1.9515295891e-4f, zy, 8.3321608736e-3f);
+              if constexpr (n == 12) pcx = __builtin_fmaf(2.443315711809948e-5f, zx, -1.388731625493765e-3f), pcy = __builtin_fmaf(2.443315711809948e-5f, zy, -1.388731625493765e-3f);
+              if constexpr (n == 13) psx = __builtin_fmaf(psx, zx, -1.6666654611e-1f), psy = __builtin_fmaf(psy, zy, -1.6666654611e-1f);
+              if constexpr (n == 14) pcx = __builtin_fmaf(pcx, zx, 4.166664568298827e-2f), pcy = __builtin_fmaf(pcy, zy, 4.166664568298827e-2f);
+              if constexpr (n == 15) psx *= zx, psy *= zy;
+              if constexpr (n == 16) pcx *= zx, pcy *= zy;
+              if constexpr (n == 17) hx = __builtin_fmaf(-0.5f, zx, 1.0f), hy = __builtin_fmaf(-0.5f, zy, 1.0f);
+              if constexpr (n == 18) snx = __builtin_fmaf(psx, rx, rx), sny = __builtin_fmaf(psy, ry, ry);
+              if constexpr (n == 19) csx = __builtin_fmaf(pcx, zx, hx), csy = __builtin_fmaf(pcy, zy, hy);
+              if constexpr (n == 20) ex = (qx & 1) == 0, ey = (qy & 1) == 0;
+              // (the compares a slot ahead of the selects that read them: no wait states in between)
+              if constexpr (n == 21) nx = (qx & 2) == 0, ny = (qy & 2) == 0;
+              if constexpr (n == 22) ax = ex ? snx : csx, ay = ey ? sny : csy;
+              if constexpr (n == 23) sx = nx ? ax : -ax, sy = ny ? ay : -ay;
+              if constexpr (n == 25) smax = fmaxf(smax, fmaxf(fabsf(sx), fabsf(sy)));  // (a use in front of the range check: nothing sinks behind it)
+              if constexpr (n == 24) out[ti][r0] = sx, out[ti][r0 + 1] = sy;
+              // (26: a spare slot of the inference form)
+              if constexpr (n == 27) ax = ex ? csx : snx, ay = ey ? csy : sny;
+              if constexpr (n == 28) nx = ((qx + 1) & 2) == 0, ny = ((qy + 1) & 2) == 0;
+              if constexpr (n == 29) cx = nx ? ax : -ax, cy = ny ? ay : -ay;
+              if constexpr (n == 30) dd[r0 & 3] = w0 * cx, dd[(r0 & 3) + 1] = w0 * cy;
+            };
+            if constexpr (ep) bx = bnx, by = bny;
+            static_for<12>([&](auto k_c) {
+              constexpr int k = decltype(k_c)::value;
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (mm) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                constexpr int j = k / 6, t = k % 6, kk = mm ? ks + j : 0;
+                const x3::Frag& w = wf[j];
+                const x3::Frag& v = cur[kk];
+                f32x16& c = acc[i & 1];
+                if constexpr (t == 0) c = mfma(w.h, v.l, first && j == 0 ? zero : c);
+                if constexpr (t == 1) c = mfma(w.l, v.h, c);
+                if constexpr (t == 2) c = mfma(w.m, v.m, c);
+                if constexpr (t == 3) c = mfma(w.h, v.m, c);
+                if constexpr (t == 4) c = mfma(w.m, v.h, c);
+                if constexpr (t == 5) c = mfma(w.h, v.h, c);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (k == 6) {
+                // the bias pair of the NEXT slice (its first use is a region away: no wait catches the fragment reads
+                // that follow it in the LDS queue)
+                constexpr int npj = (pj + 1) & 7, nti = pj == 7 ? i : ti, nr0 = 2 * npj;
+                if constexpr (nti < kTiles && (ep || pj == 7)) {
+                  const f32x2 b01 = *reinterpret_cast<const f32x2*>(&sm.bias[l][32 * nti + (nr0 & 3) + 8 * (nr0 >> 2) + feat0]);
+                  bnx = b01.x, bny = b01.y;
+                }
+              }
+              if constexpr (STORE) {
+                // The stores, a region behind the values.  A quad is complete at the end of an odd slice: it is staged
+                // in the next region, behind the wait in front of MFMA 7 (no wait then sees a young LDS write); a half
+                // row (two quads) leaves two regions later: a in one region, w0 cos in the next, read behind MFMA 2 and
+                // stored behind MFMA 6 (the wait in front of the store finds requests that are four gaps old).
+                constexpr int qt = pj == 0 ? i - 2 : ti, qq = pj == 0 ? 3 : (pj >> 1) - 1;  // the quad to stage here
+                if constexpr (k == 7 && (pj & 1) == 0 && qt >= 0 && (pj > 0 || i >= 2)) {
+                  stage(0, qq, f32x4{out[qt][4 * qq], out[qt][4 * qq + 1], out[qt][4 * qq + 2], out[qt][4 * qq + 3]});
+                  stage(1, qq, f32x4{dd[0], dd[1], dd[2], dd[3]});
+                }
+                // flushes: half 0 of tile ti in slices 5 (a) and 6 (w0 cos); half 1 of tile i - 2 in slices 1 and 2
+                constexpr bool f0 = ep && (pj == 5 || pj == 6), f1 = i >= 2 && (pj == 1 || pj == 2);
+                constexpr int ft = f0 ? ti : i - 2, fh = f0 ? 0 : 1, fa = (pj == 5 || pj == 1) ? 0 : 1;
+                if constexpr ((f0 || f1) && k == 1) unstage(fa, fh, fl);
+                if constexpr ((f0 || f1) && k == 5) put(fa ? gd : ga, ft, fh, fl);
+              }
+              if constexpr (mm && k == 0) wf[1] = read_wfrag(tB);
+              if constexpr (have_next && k == 6) wf[0] = read_wfrag(nA);
+#ifndef RR_EXPERIMENT_NO_EPILOGUE  // timing experiment only (results are then wrong)
+              if constexpr (ep) static_for<kOps>([&](auto n_c) {
+                if constexpr (decltype(n_c)::value * 12 / kOps == k) op(n_c);
+              });
+#else
+              if constexpr (ep && k == 11) out[ti][r0] = acc[ti & 1][r0], out[ti][r0 + 1] = acc[ti & 1][r0 + 1];
+#endif
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+        if constexpr (i == kTiles) RP_MARK(4)  // the last tile's epilogue, alone
+        if constexpr (i > 0) {
+          // ---- range check of tile i - 1 (wave-uniform, never taken by a trained network) --------------------------
+          constexpr int ti = i - 1;
+          if (__builtin_amdgcn_ballot_w64(!(amax <= 8192.0f) || !(smax <= 2.0f)) != 0) {
+            float* fix = &sm.stg[wave][0][0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int f = 32 * ti + (r & 3) + 8 * (r >> 2) + feat0;
+              float v = acc[ti & 1][r];
+              asm volatile("" : "+v"(v));  // (opaque: or the slices' arguments are kept alive -- spilled -- for this path)
+              fix[r * 64 + lane] = w0 * (v + sm.bias[l][f]);
+            }
+            repair_values(fix, 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ti][r] = fix[r * 64 + lane];
+            if (STORE) {
+              // where the normal path stands: quads 0, 1 have left (wrong), quad 2 is staged (these bytes: gone), quad 3 waits
+              // in `out` / `dd`.  Quads 0, 1 again, straight from the registers; quad 2 staged again; dd corrected.
+              float dq[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dq[r] = w0 * fix[(16 + r) * 64 + lane];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<f32x4*>(ga + row * kH + feat0 + 32 * ti + 8 * q) =
+                    f32x4{out[ti][4 * q], out[ti][4 * q + 1], out[ti][4 * q + 2], out[ti][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(gd + row * kH + feat0 + 32 * ti + 8 * q) =
+                    f32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]};
+              }
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch has been read: its bytes are the image again
+              stage(0, 2, f32x4{out[ti][8], out[ti][9], out[ti][10], out[ti][11]});
+              stage(1, 2, f32x4{dq[8], dq[9], dq[10], dq[11]});
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dd[e] = dq[12 + e];
+            }
+          }
+          amax = 0.f, smax = 0.f;
+        }
+      });
+      if (STORE) {  // the last tile's quad 3 and second half row
+        constexpr int t = kTiles - 1;
+        stage(0, 3, f32x4{out[t][12], out[t][13], out[t][14], out[t][15]});
+        stage(1, 3, f32x4{dd[0], dd[1], dd[2], dd[3]});
+        f32x4 va[2], vd[2];
+        unstage(0, 1, va), unstage(1, 1, vd);
+        put(ga, t, 1, va), put(gd, t, 1, vd);
+      }
+    }
+
+    RP_MARK(2)
+    // ---- head: y[row] = a_last[row] . w_last + b_last; the lane halves hold the two halves of the features -----------
+    {
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < kTiles; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(&sm.w_last[32 * i + 8 * q + feat0]);
+          part += out[i][4 * q] * w4.x, part += out[i][4 * q + 1] * w4.y;
+          part += out[i][4 * q + 2] * w4.z, part += out[i][4 * q + 3] * w4.w;
+        }
+      part += __shfl_xor(part, 32, 64);
+      const float yv = part + b_last;
+      if (lh == 0) a.y[row] = yv;
+      if constexpr (LOSS) {
+        // ---- loss and the head's backward (models.py:64 F.mse_loss: mean((y - target)^2); dLoss/dy = 2 (y - t) / N):
+        // dz = dy w_head (.) w0 cos, dW_head += dy^T a, db_last += colsum(dz).  Rows beyond n repeat row n - 1 (same dz to
+        // the same address) and add nothing to the sums.
+        const bool live = g * kRows + 32 * wave + l31 < a.n;
+        const float diff = yv - a.target[row], dyv = diff * a.grad_scale, dys = live ? dyv : 0.f;
+        if (live && lh == 0) g_loss += diff * diff, g_bhead += dyv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // w0 cos of this group has reached L2 (other lanes stored this lane's row)
+        const float* __restrict__ gz = a.dz_last + row * kH + feat0;
+        float pw = 0.f, pb = 0.f;  // the even tile's reduced sums, waiting for the odd one
+#pragma unroll
+        for (int i = 0; i < kTiles; ++i) {
+          f32x4 dq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const f32x4*>(gz + 32 * i + 8 * q);
+          float P[16], Q[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&sm.w_last[32 * i + 8 * q + feat0]);
+            f32x4 z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              z[e] = (dyv * w4[e]) * dq[q][e];
+              P[4 * q + e] = dys * out[i][4 * q + e];
+              Q[4 * q + e] = live ? z[e] : 0.f;
+            }
+            stage(0, q, z);
+          }
+          // (only rows below n: a repeated row may have read dz where it expected w0 cos -- another wave owns that row)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 vz[2];
+            unstage(0, h, vz);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (g * kRows + 32 * wave + (lane >> 2) + 16 * j < a.n)
+                *reinterpret_cast<f32x4*>(a.dz_last + goff[j] + 32 * i + 16 * h) = vz[j];
+          }
+          // sums over the wave's 32 rows: a halving butterfly over the lanes (register 2 j + bit stays, the other one travels)
+          float sw = reduce16(P, lane), sb = reduce16(Q, lane);  // lane & 15 = the accumulator register the lane now holds
+          if (i & 1) {  // ... and tile i - 1 / tile i over bit 4
+            const bool up = (lane & 16) != 0;
+            const float tw = __shfl_xor(up ? pw : sw, 16, 64), tb = __shfl_xor(up ? pb : sb, 16, 64);
+            g_wh[i >> 1] += (up ? sw : pw) + tw, g_bl[i >> 1] += (up ? sb : pb) + tb;
+          } else {
+            pw = sw, pb = sb;
+          }
+        }
+        park();
+      }
+    }
+    RP_MARK(5)  // head
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunks queued behind the last one land before the LDS is released
+  RP_END
+  if constexpr (LOSS) {
+    // ---- this workgroup's slab: dW_head [H] | db_last [H] | db_head, loss.  A lane holds, for j = 0 .. 3, the sums of
+    // accumulator register (lane & 15) of tile 2 j + ((lane >> 4) & 1): feature 32 tile + (r & 3) + 8 (r >> 2) + 4 lh.
+    __syncthreads();  // (the ring is free: every chunk has landed, every wave is past its last read)
+    float* red = reinterpret_cast<float*>(&sm.ring[0][0]);  // [wave][2][H], then [2][4 waves]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = lane & 15, f = 32 * (2 * j + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      red[(wave * 2 + 0) * kH + f] = g_wh[j];
+      red[(wave * 2 + 1) * kH + f] = g_bl[j];
+    }
+    // lane halves: every lane of a half added its own row's terms; lh == 0 lanes hold them (see above)
+    float sb = g_bhead, sl = g_loss;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sb += __shfl_xor(sb, off, 64), sl += __shfl_xor(sl, off, 64);
+    if (lane == 0) red[8 * kH + wave] = sb, red[8 * kH + 4 + wave] = sl;
+    __syncthreads();
+    float* slab = a.partial + (int64_t)blockIdx.x * fwd_slab_floats(kH);
+    {
+      const int f = tid;  // 256 threads = H
+      slab[f] = ((red[0 * kH + f] + red[2 * kH + f]) + red[4 * kH + f]) + red[6 * kH + f];
+      slab[kH + f] = ((red[1 * kH + f] + red[3 * kH + f]) + red[5 * kH + f]) + red[7 * kH + f];
+    }
+    if (tid == 0) {
+      slab[2 * kH] = ((red[8 * kH] + red[8 * kH + 1]) + red[8 * kH + 2]) + red[8 * kH + 3];
+      slab[2 * kH + 1] = (((red[8 * kH + 4] + red[8 * kH + 5]) + red[8 * kH + 6]) + red[8 * kH + 7]) * a.inv_n;
+      slab[2 * kH + 2] = 0.f, slab[2 * kH + 3] = 0.f;
+    }
+  }
+}
+
+}  // namespace rr
+}  // namespace
+
+bool rows_supported(int hidden, int n_sine) { return hidden == rr::kH && n_sine >= 2; }
+int rows_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, rr::kRows), 256); }
+
+int forward_rows(const ChainArgs& a, int mode, hipStream_t st) {
+  const int blocks = rows_blocks(a.n);  // one workgroup per CU
+  if (mode == 2)
+    hipLaunchKernelGGL((rr::siren_forward_rows_kernel<2>), dim3(blocks), dim3(rr::kThreadsR), 0, st, a);
+  else if (mode == 1)
+    hipLaunchKernelGGL((rr::siren_forward_rows_kernel<1>), dim3(blocks), dim3(rr::kThreadsR), 0, st, a);
+  else if (mode == 0)
+    hipLaunchKernelGGL((rr::siren_forward_rows_kernel<0>), dim3(blocks), dim3(rr::kThreadsR), 0, st, a);
+  else
+    return fail(MRI_ERR_INVALID_ARGUMENT, "forward_rows: mode %d", mode);
+  return check_launch("siren_forward_rows_kernel");
+}
+
+#ifdef SIREN_PROFILE
+extern "C" int mri_debug_set_rows_profile(long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rr::g_rows_profile), &device_buffer, sizeof(device_buffer)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int backward_rows(const BwdArgs&, hipStream_t) { return fail(MRI_ERR_INVALID_ARGUMENT, "backward_rows: not built"); }
+
+}  // namespace mri

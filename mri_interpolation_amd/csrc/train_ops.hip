@@ -258,6 +258,8 @@ extern "C" int mri_set_option(const char* name, int32_t value) {
   } else if (!strcmp(name, "bwd_records")) {
     MRI_REQUIRE(value == 0 || value == 1, "bwd_records %d not in {0, 1}", value);
     options().bwd_records = value;
+  } else if (!strcmp(name, "siren_rows")) {
+    options().siren_rows = value != 0;
   } else if (!strcmp(name, "bwd_blocks_per_level")) {
     options().bwd_blocks_per_level = value < 1 ? 1 : value;
   } else {

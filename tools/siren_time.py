@@ -3,7 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mri_interpolation_amd import _lib, models, ops, trainer
-_lib.load()
+lib = _lib.load()
+if os.environ.get('MRI_SIREN_ROWS') == '0':
+    lib.mri_set_option(b'siren_rows', 0)
 hidden = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 net = models.SirenNet(3, hidden, 1, 5).cuda()
 st = trainer.FusedStep(net, net.configure_optimizers())
