@@ -29,6 +29,7 @@ struct ChainArgs {
   float* dz_last;                   // (n, H): dLoss / d(pre-activation of the last sine layer)
   float* partial;                   // [gridDim.x][fwd_slab_floats]
   const char* wsplit;               // split W of layers 1 .. n_sine-1 (split_matrix_bytes each)
+  float* dy_ws;                     // siren_rows.hip, loss mode: dLoss/dy per row, in the workspace (rows_dy_offset)
 };
 
 // loss-mode slab: dW_head [H] | db_last [H] | db_head, loss (padded to 4)
@@ -53,6 +54,7 @@ struct BwdArgs {
   float* partial;                  // [gridDim.x][bwd_slab_floats]
   const char* wtsplit;             // split W^T of layers 1 .. n_sine-1 (split_matrix_bytes each)
   int head_done;                   // dz[n_sine-1] is an INPUT (the forward kernel's loss mode wrote it)
+  const float* dy_ws;              // siren_rows.hip: dLoss/dy per row, where the loss-mode forward kernel left it
 };
 
 // slab: dW_head [H] | db_head [1] (padded to 4) | db_l [n_sine][H] | dW_first [H][kMaxIn]
@@ -63,8 +65,10 @@ __host__ __device__ inline int bwd_slab_floats(int hidden, int n_sine) {
 
 // siren_rows.hip
 bool rows_supported(int hidden, int n_sine);
+int64_t rows_dy_offset(int64_t n, int hidden, int n_sine);  // bytes into the workspace's slab region
 int rows_blocks(int64_t n);
 int forward_rows(const ChainArgs& a, int mode, hipStream_t st);
+bool rows_backward_supported(int hidden, int n_sine, int dim_in, int head_done);
 int backward_rows(const BwdArgs& a, hipStream_t st);
 
 }  // namespace mri

@@ -1039,7 +1039,10 @@ int launch_wgrad(const WgradArgs& g, float* d_weight, hipStream_t st) {
 }
 
 int forward_any(int hidden, const ChainArgs& a, int mode, hipStream_t st) {
-  if (options().siren_rows && rows_supported(hidden, a.n_sine)) return forward_rows(a, mode, st);
+  // (the loss mode hands over to the rows backward kernel: both or neither)
+  if (options().siren_rows && rows_supported(hidden, a.n_sine) &&
+      (mode != 2 || rows_backward_supported(hidden, a.n_sine, a.dim_in, 1)))
+    return forward_rows(a, mode, st);
   switch (hidden) {
     case 32: return launch_forward<32>(a, mode, st);
     case 64: return launch_forward<64>(a, mode, st);
@@ -1170,6 +1173,7 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   a.x = x, a.n = n, a.dim_in = dim_in, a.n_sine = n_sine_layers;
   a.w0_first = w0_first, a.w0 = w0, a.y = y;
   a.target = target, a.dz_last = dz_last, a.partial = static_cast<float*>(workspace);
+  a.dy_ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + rows_dy_offset(n, hidden, n_sine_layers));
   a.grad_scale = (float)(2.0 / ((double)n_total * (double)grad_divisor));
   a.inv_n = (float)(1.0 / (double)n_total);
   for (int l = 0; l <= n_sine_layers; ++l) {
@@ -1188,7 +1192,7 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   if (int rc = forward_any(hidden, a, 2, st)) return rc;
   FwdReduceArgs r{};
   r.partial = a.partial, r.hidden = hidden;
-  r.slabs = options().siren_rows && rows_supported(hidden, n_sine_layers) ? rows_blocks(n) : blocks;
+  r.slabs = options().siren_rows && rows_backward_supported(hidden, n_sine_layers, dim_in, 1) ? rows_blocks(n) : blocks;
   r.d_w_head = d_w_head, r.d_b_head = d_b_head, r.d_b_last = d_b_last, r.loss_out = loss_out;
   hipLaunchKernelGGL(siren_fwd_reduce_kernel, dim3((unsigned)ceil_div(fwd_slab_floats(hidden), 256)),
                      dim3(256), 0, st, r);
@@ -1200,7 +1204,10 @@ namespace {
 int64_t slab_region_bytes(int64_t n, int hidden, int n_sine) {
   const int64_t chain = (int64_t)chain_blocks(hidden, n) * bwd_slab_floats(hidden, n_sine);
   const int64_t wgrad = n_sine > 1 ? (int64_t)wgrad_blocks(n) * wgrad_split(hidden) * hidden * hidden : 0;
-  return (std::max(chain, wgrad) * 4 + 255) / 256 * 256;
+  int64_t bytes = std::max(chain, wgrad) * 4;
+  // siren_rows.hip: dLoss/dy per row travels from the loss-mode forward to the backward kernel behind the slabs
+  if (rows_supported(hidden, n_sine)) bytes = std::max(bytes, rows_dy_offset(n, hidden, n_sine) + n * 4);
+  return (bytes + 255) / 256 * 256;
 }
 }  // namespace
 }  // namespace mri
@@ -1236,6 +1243,7 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   BwdArgs a{};
   a.x = x, a.dy = dy, a.n = n, a.dim_in = dim_in, a.n_sine = L;
   a.partial = static_cast<float*>(workspace);
+  a.dy_ws = reinterpret_cast<const float*>(static_cast<const char*>(workspace) + rows_dy_offset(n, hidden, L));
   for (int l = 0; l <= L; ++l) {
     MRI_REQUIRE(weight[l] && d_weight[l] && d_bias[l], "NULL parameter / gradient pointer (layer %d)", l);
     MRI_REQUIRE((reinterpret_cast<uintptr_t>(weight[l]) & 15) == 0, "weights must be 16-byte aligned");
@@ -1255,9 +1263,10 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   a.head_done = head_done ? 1 : 0;
   a.wtsplit = wtsplit;
   if (int rc = split_weights(weight, L, hidden, true, wtsplit, st)) return rc;
-  if (int rc = backward_any(hidden, a, st)) return rc;
+  const bool rows = options().siren_rows && rows_backward_supported(hidden, L, dim_in, head_done);
+  if (int rc = rows ? backward_rows(a, st) : backward_any(hidden, a, st)) return rc;
   BwdReduceArgs r{};
-  r.partial = a.partial, r.slabs = chain_blocks(hidden, n), r.hidden = hidden, r.n_sine = L;
+  r.partial = a.partial, r.slabs = rows ? rows_blocks(n) : chain_blocks(hidden, n), r.hidden = hidden, r.n_sine = L;
   r.dim_in = dim_in;
   for (int l = 0; l <= L; ++l) r.d_w[l] = d_weight[l], r.d_b[l] = d_bias[l];
   hipLaunchKernelGGL(siren_bwd_reduce_kernel,

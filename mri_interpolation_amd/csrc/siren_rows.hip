@@ -130,26 +130,31 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // Sum each of 16 registers over the 16 lanes that share (lane >> 4): a halving butterfly -- per step a lane keeps one
-// register of a pair and sends the other to its partner; lane (lane & 15) = r ends up with the sum of register r.
+// register of a pair and sends the other to its partner; lane (lane & 15) = r ends up with the sum of register r.  The
+// exchanges are DPP modifiers (lane ^ 1, ^ 2: quad permutes; ^ 4 = half-row mirror then quad reverse; ^ 8 = row mirror then
+// half-row mirror): no LDS round trip -- with __shfl_xor (ds_bpermute, every result behind an lgkmcnt(0)) one call took
+// 1.4 k cycles, and a group's tail makes 8 to 64 of them.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
+  const bool u1 = (lane & 1) != 0, u2 = (lane & 2) != 0, u4 = (lane & 4) != 0, u8 = (lane & 8) != 0;
   float a8[8], a4[4], a2[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const bool up = (lane & 1) != 0;
-    a8[j] = (up ? v[2 * j + 1] : v[2 * j]) + __shfl_xor(up ? v[2 * j] : v[2 * j + 1], 1, 64);
-  }
+  for (int j = 0; j < 8; ++j) a8[j] = (u1 ? v[2 * j + 1] : v[2 * j]) + dpp<0xB1>(u1 ? v[2 * j] : v[2 * j + 1]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool up = (lane & 2) != 0;
-    a4[j] = (up ? a8[2 * j + 1] : a8[2 * j]) + __shfl_xor(up ? a8[2 * j] : a8[2 * j + 1], 2, 64);
-  }
+  for (int j = 0; j < 4; ++j) a4[j] = (u2 ? a8[2 * j + 1] : a8[2 * j]) + dpp<0x4E>(u2 ? a8[2 * j] : a8[2 * j + 1]);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const bool up = (lane & 4) != 0;
-    a2[j] = (up ? a4[2 * j + 1] : a4[2 * j]) + __shfl_xor(up ? a4[2 * j] : a4[2 * j + 1], 4, 64);
-  }
-  const bool up = (lane & 8) != 0;
-  return (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], 8, 64);
+  for (int j = 0; j < 2; ++j) a2[j] = (u4 ? a4[2 * j + 1] : a4[2 * j]) + dpp<0x1B>(dpp<0x141>(u4 ? a4[2 * j] : a4[2 * j + 1]));
+  return (u8 ? a2[1] : a2[0]) + dpp<0x141>(dpp<0x140>(u8 ? a2[0] : a2[1]));
+}
+// ... and over bit 4 of the lane for a pair of tiles: lanes with the bit clear end up with the even tile's sum over the
+// wave's 32 rows, the others with the odd tile's (v_permlane16_swap exchanges the odd rows of one register with the even
+// rows of the other)
+__device__ __forceinline__ float pair32(float even, float odd) {
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(even), __float_as_uint(odd), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
 }
 
 // Cold path: sin / cos of 32 arguments per lane staged in LDS, by the library routine.
@@ -168,17 +173,20 @@ __device__ __attribute__((noinline)) void repair_values(float* fix, int count) {
 // to nothing): shader-clock cycles per phase, per wave.
 #ifdef SIREN_PROFILE
 __device__ long long* g_rows_profile = nullptr;
+__device__ long long* g_rows_profile_bwd = nullptr;
 #define RP_BEGIN long long rp_t = clock64(); long long rp_acc[8] = {};
 #define RP_MARK(i) { const long long rp_n = clock64(); rp_acc[i] += rp_n - rp_t; rp_t = rp_n; }
-#define RP_END                                                                          \
-  if (g_rows_profile && (threadIdx.x & 63) == 0) {                                      \
-    long long* dst = g_rows_profile + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
-    for (int q = 0; q < 8; ++q) dst[q] = rp_acc[q];                                     \
+#define RP_END_TO(buf)                                                       \
+  if (buf && (threadIdx.x & 63) == 0) {                                        \
+    long long* dst = buf + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; \
+    for (int q = 0; q < 8; ++q) dst[q] = rp_acc[q];                            \
   }
+#define RP_END RP_END_TO(g_rows_profile)
 #else
 #define RP_BEGIN
 #define RP_MARK(i)
 #define RP_END
+#define RP_END_TO(buf)
 #endif
 
 // MODE 0: inference; 1: training (a and w0 cos of every layer leave for HBM); 2: training with the loss (siren_chain.hip's
@@ -222,12 +230,12 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // parameters and chunk 0 .. 2 are in LDS
 
-  float g_wh[4] = {0.f, 0.f, 0.f, 0.f}, g_bl[4] = {0.f, 0.f, 0.f, 0.f}, g_bhead = 0.f, g_loss = 0.f;  // loss mode: running sums of this lane
+  float g_wh[4] = {0.f, 0.f, 0.f, 0.f}, g_bhead = 0.f, g_loss = 0.f;  // loss mode: running sums of this lane
   // (parked in accumulation registers between the groups' tails: the tile loop has no vector register to spare)
   auto park = [&]() {
     if constexpr (LOSS) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(g_wh[j]), "+a"(g_bl[j]));
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(g_wh[j]));
       asm volatile("" : "+a"(g_bhead), "+a"(g_loss));
     }
   };
@@ -327,9 +335,12 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
       const float w0 = a.w0;
 
       // the layer's operand: k-step ks contracts features 16 ks + 4 lh + (j & 3) + 8 (j >> 2) = registers 8 (ks & 1) + j of tile ks / 2
+      // (only the first region's two fragments here: the other fourteen are split in the gaps of tile 0's MFMAs, a region
+      // ahead of their use -- tile 0 has no epilogue to carry, and the split of all sixteen in front of the tile loop was
+      // 5 k cycles per layer with the matrix pipe idle)
       x3::Frag cur[kSteps];
 #pragma unroll
-      for (int ks = 0; ks < kSteps; ++ks) {
+      for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = out[ks >> 1][8 * (ks & 1) + j];
@@ -367,7 +378,14 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               // ---- chunk p + 1 has landed for everyone, chunk p - 1's slot is free (chunk p + 3 goes there, below) ----
               __builtin_amdgcn_sched_barrier(0);
               RP_MARK(2)  // MFMAs + interleaved epilogue
-              asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // at most chunk p + 2's six pieces behind it
+              // Chunk p + 1 was queued three syncs ago; what this wave has queued since (never fewer): chunk p + 2's six
+              // pieces and, in the training forms, the two stores of each half-row flush in between (slices 1, 2 from the
+              // layer's third tile on, slices 5, 6 from its second).  Counting them keeps the wait off stores that are a
+              // region old (a plain vmcnt(6) made every sync wait for those to be acknowledged).
+              constexpr int younger = 6 + (STORE ? (i >= 2 ? 8 : (i == 1 && rg == 3 && hf == 1 ? 4 : 0)) : 0);
+              if constexpr (younger == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+              if constexpr (younger == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+              if constexpr (younger == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
               __builtin_amdgcn_s_barrier();
               RP_MARK(3)  // chunk wait + barrier
             }
@@ -482,6 +500,17 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               }
               if constexpr (mm && k == 0) wf[1] = read_wfrag(tB);
               if constexpr (have_next && k == 6) wf[0] = read_wfrag(nA);
+              if constexpr (i == 0 && 2 * pj + 2 < kSteps) {
+                // ---- tile 0: the operand fragments of the NEXT region's two k-steps, a pair of values per gap ----------
+                constexpr int sk = 2 * pj + 2 + (k >> 2 & 1), sq = k & 3;  // gaps 0-3: k-step 2 pj + 2, gaps 4-7: 2 pj + 3
+                if constexpr (k < 8) {
+                  uint32_t h, m, l2;
+                  x3::split2(out[sk >> 1][8 * (sk & 1) + 2 * sq], out[sk >> 1][8 * (sk & 1) + 2 * sq + 1], h, m, l2);
+                  cur[sk].h[sq] = h, cur[sk].m[sq] = m, cur[sk].l[sq] = l2;
+                }
+                if constexpr (k == 8) asm("" : "+a"(cur[2 * pj + 2].h), "+a"(cur[2 * pj + 2].m), "+a"(cur[2 * pj + 2].l));
+                if constexpr (k == 9) asm("" : "+a"(cur[2 * pj + 3].h), "+a"(cur[2 * pj + 3].m), "+a"(cur[2 * pj + 3].l));
+              }
 #ifndef RR_EXPERIMENT_NO_EPILOGUE  // timing experiment only (results are then wrong)
               if constexpr (ep) static_for<kOps>([&](auto n_c) {
                 if constexpr (decltype(n_c)::value * 12 / kOps == k) op(n_c);
@@ -558,62 +587,36 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
       const float yv = part + b_last;
       if (lh == 0) a.y[row] = yv;
       if constexpr (LOSS) {
-        // ---- loss and the head's backward (models.py:64 F.mse_loss: mean((y - target)^2); dLoss/dy = 2 (y - t) / N):
-        // dz = dy w_head (.) w0 cos, dW_head += dy^T a, db_last += colsum(dz).  Rows beyond n repeat row n - 1 (same dz to
-        // the same address) and add nothing to the sums.
+        // ---- loss (models.py:64 F.mse_loss: mean((y - target)^2); dLoss/dy = 2 (y - t) / N) and what of the head's
+        // backward needs a: dW_head += dy^T a.  dy goes to the workspace: siren_backward_rows_kernel starts from it and
+        // from the w0 cos this kernel left in dz_last (dz = dy w_head (.) w0 cos, db_last: there -- re-reading w0 cos
+        // here, a tile per round trip, cost 0.6 ms at config 3).  Rows beyond n repeat row n - 1 and add nothing.
         const bool live = g * kRows + 32 * wave + l31 < a.n;
         const float diff = yv - a.target[row], dyv = diff * a.grad_scale, dys = live ? dyv : 0.f;
+        if (lh == 0) a.dy_ws[row] = dyv;
         if (live && lh == 0) g_loss += diff * diff, g_bhead += dyv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // w0 cos of this group has reached L2 (other lanes stored this lane's row)
-        const float* __restrict__ gz = a.dz_last + row * kH + feat0;
-        float pw = 0.f, pb = 0.f;  // the even tile's reduced sums, waiting for the odd one
+        float pw = 0.f;  // the even tile's reduced sums, waiting for the odd one
 #pragma unroll
         for (int i = 0; i < kTiles; ++i) {
-          f32x4 dq[4];
+          float P[16];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const f32x4*>(gz + 32 * i + 8 * q);
-          float P[16], Q[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&sm.w_last[32 * i + 8 * q + feat0]);
-            f32x4 z;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              z[e] = (dyv * w4[e]) * dq[q][e];
-              P[4 * q + e] = dys * out[i][4 * q + e];
-              Q[4 * q + e] = live ? z[e] : 0.f;
-            }
-            stage(0, q, z);
-          }
-          // (only rows below n: a repeated row may have read dz where it expected w0 cos -- another wave owns that row)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            f32x4 vz[2];
-            unstage(0, h, vz);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (g * kRows + 32 * wave + (lane >> 2) + 16 * j < a.n)
-                *reinterpret_cast<f32x4*>(a.dz_last + goff[j] + 32 * i + 16 * h) = vz[j];
-          }
-          // sums over the wave's 32 rows: a halving butterfly over the lanes (register 2 j + bit stays, the other one travels)
-          float sw = reduce16(P, lane), sb = reduce16(Q, lane);  // lane & 15 = the accumulator register the lane now holds
-          if (i & 1) {  // ... and tile i - 1 / tile i over bit 4
-            const bool up = (lane & 16) != 0;
-            const float tw = __shfl_xor(up ? pw : sw, 16, 64), tb = __shfl_xor(up ? pb : sb, 16, 64);
-            g_wh[i >> 1] += (up ? sw : pw) + tw, g_bl[i >> 1] += (up ? sb : pb) + tb;
-          } else {
-            pw = sw, pb = sb;
-          }
+          for (int r = 0; r < 16; ++r) P[r] = dys * out[i][r];
+          // sums over the wave's 32 rows: a halving butterfly over the lanes (reduce16), then tile i - 1 / tile i over bit 4
+          const float sw = reduce16(P, lane);
+          if (i & 1)
+            g_wh[i >> 1] += pair32(pw, sw);
+          else
+            pw = sw;
         }
         park();
       }
     }
-    RP_MARK(5)  // head
+    RP_MARK(5)  // head (+ loss tail)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunks queued behind the last one land before the LDS is released
   RP_END
   if constexpr (LOSS) {
-    // ---- this workgroup's slab: dW_head [H] | db_last [H] | db_head, loss.  A lane holds, for j = 0 .. 3, the sums of
+    // ---- this workgroup's slab: dW_head [H] | db_last [H] (zero: the backward kernel's) | db_head, loss.  A lane holds, for j = 0 .. 3, the sums of
     // accumulator register (lane & 15) of tile 2 j + ((lane >> 4) & 1): feature 32 tile + (r & 3) + 8 (r >> 2) + 4 lh.
     __syncthreads();  // (the ring is free: every chunk has landed, every wave is past its last read)
     float* red = reinterpret_cast<float*>(&sm.ring[0][0]);  // [wave][2][H], then [2][4 waves]
@@ -621,7 +624,6 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
     for (int j = 0; j < 4; ++j) {
       const int r = lane & 15, f = 32 * (2 * j + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + 4 * lh;
       red[(wave * 2 + 0) * kH + f] = g_wh[j];
-      red[(wave * 2 + 1) * kH + f] = g_bl[j];
     }
     // lane halves: every lane of a half added its own row's terms; lh == 0 lanes hold them (see above)
     float sb = g_bhead, sl = g_loss;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
     {
       const int f = tid;  // 256 threads = H
       slab[f] = ((red[0 * kH + f] + red[2 * kH + f]) + red[4 * kH + f]) + red[6 * kH + f];
-      slab[kH + f] = ((red[1 * kH + f] + red[3 * kH + f]) + red[5 * kH + f]) + red[7 * kH + f];
+      slab[kH + f] = 0.f;
     }
     if (tid == 0) {
       slab[2 * kH] = ((red[8 * kH] + red[8 * kH + 1]) + red[8 * kH + 2]) + red[8 * kH + 3];
@@ -643,11 +645,386 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward chain, same ownership: a wave's 32 rows of dz stay in registers from the last sine layer down to the first.
+// Per H x H layer l: da_{l-1}^T = W_l^T dz_l^T (the split W^T planes are the MFMA's A operand, streamed through the same
+// chunk ring; dz_l in the accumulator layout is the B operand after its split), dz_{l-1} = da_{l-1} (.) w0 cos_{l-1} in the
+// gaps of the next tile's MFMAs -- the derivative tile arrives by LDS-DMA as the rows lie in HBM (16 lanes x 64 bytes per
+// instruction) and is read back a row per lane; dz_{l-1} (l - 1 >= 1: the weight gradient kernel contracts it with
+// a_{l-2} over the batch) leaves through the staging image.  Bias gradients = column sums over the rows = sums over
+// the LANES: a halving butterfly per tile after the layer's tile loop, accumulated by sole owners in LDS per (layer, wave);
+// the first layer's weight gradient dz_0^T x likewise, in registers.  Serves the training path only: the head's backward
+// was done by the loss-mode forward kernel (head_done), dim_in <= 4.
+struct SmemB {
+  float gb[kMaxSine - 1][4][kH];  // bias-gradient column sums of sine layers 0 .. L-2 per wave
+  float w_last[kH];
+  float stg[4][32 * kStgLd];      // dz of a tile on its way out
+  char din[4][4096];              // w0 cos of a tile on its way in: [half][16-row block][16 rows][64 bytes]
+  char ring[kRing][kChunk] __attribute__((aligned(16)));
+};
+
+__global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const BwdArgs a) {
+  __shared__ SmemB sm;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int L = a.n_sine, n_mm = L - 1;  // >= 1 H x H layers
+  for (int e = tid; e < (kMaxSine - 1) * 4 * kH; e += kThreadsR) (&sm.gb[0][0][0])[e] = 0.f;
+  for (int e = tid; e < kH; e += kThreadsR) sm.w_last[e] = a.w[L][e];
+  const int64_t groups = (a.n + kRows - 1) / kRows;
+  int wslot[kRing];
+#pragma unroll
+  for (int q = 0; q < kRing; ++q) {
+    wslot[q] = q * kChunk + 32 * l31 + 16 * (lh ^ ((l31 >> 3) & 1));
+    asm volatile("" : "+v"(wslot[q]));
+  }
+  const char* const ring0 = &sm.ring[0][0];
+  const int feat0 = 4 * lh;
+  const char* const mat_top = a.wtsplit + (int64_t)(L - 2) * split_matrix_bytes(kH);  // W^T of the last sine layer: a group's first
+
+  if ((int64_t)blockIdx.x < groups) {
+    issue(mat_top, 0, 0, sm.ring[0], wave, lane);
+    issue(mat_top, 0, 1, sm.ring[1], wave, lane);
+    issue(mat_top, 1, 0, sm.ring[2], wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // first layer's weight gradient [input d][pair of tiles] and the last sine layer's bias gradient, parked in
+  // accumulation registers between their phases
+  float g_wf[4][4], g_bl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g_wf[d][j] = 0.f;
+  auto park = [&]() {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(g_wf[d][j]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(g_bl[j]));
+  };
+  park();
+  // this lane's piece of the derivative image: DMA side (16 lanes x 64 bytes per instruction) and read side (its row)
+  float* const stg_w = &sm.stg[wave][0];
+  char* const din_w = &sm.din[wave][0];
+  const int wr = l31 * kStgLd + feat0, rd = (lane >> 2) * kStgLd + 4 * (lane & 3);
+  const int din_rd = (l31 >> 4) * 1024 + (l31 & 15) * 64 + 16 * lh;  // + 2048 (q >> 1) + 32 (q & 1)
+
+  RP_BEGIN
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int64_t row = std::min<int64_t>(g * kRows + 32 * wave + l31, a.n - 1);
+    const bool live = g * kRows + 32 * wave + l31 < a.n;
+    int64_t goff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      goff[j] = std::min<int64_t>(g * kRows + 32 * wave + (lane >> 2) + 16 * j, a.n - 1) * kH + 4 * (lane & 3);
+    float xv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) xv[d] = d < a.dim_in ? a.x[row * a.dim_in + d] : 0.f;
+
+    // ---- the head: dz_{L-1} = dy w_head (.) w0 cos.  The loss-mode forward kernel left w0 cos of the last sine layer
+    // in dz[L-1] and dLoss/dy in the workspace; the tiles come in by LDS-DMA, two in flight (this wave's derivative
+    // image and its share of ring slot 3, free until the group's first chunk sync), and leave as dz the way they came.
+    float out[kTiles][16];
+    {
+      const float dyv = a.dy_ws[row];
+      float* const gzs = a.dz[n_mm];
+      char* const buf1 = &sm.ring[3][0] + 4096 * wave;
+      auto fetch = [&](int i) {
+        char* dst = (i & 1) ? buf1 : din_w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(gzs + goff[e & 1] + 32 * i + 16 * (e >> 1)),
+              (__attribute__((address_space(3))) void*)(dst + 1024 * e), 16, 0, 0);
+      };
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dy_ws[row] is in its register: every count below starts from nothing)
+      fetch(0), fetch(1);
+      float pb = 0.f;
+#pragma unroll
+      for (int i = 0; i < kTiles; ++i) {
+        // tile i has landed: behind it in the queue the four pieces of tile i + 1 (and stores of tile i - 1, maybe)
+        if (i + 1 < kTiles)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* src = ((i & 1) ? buf1 : din_w) + din_rd;
+        f32x4 dq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const f32x4*>(src + 2048 * (q >> 1) + 32 * (q & 1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image's bytes are free
+        if (i + 2 < kTiles) fetch(i + 2);
+        float Q[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(&sm.w_last[32 * i + 8 * q + feat0]);
+          f32x4 z;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            z[e] = (dyv * w4[e]) * dq[q][e];
+            out[i][4 * q + e] = z[e];
+            Q[4 * q + e] = live ? z[e] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(stg_w + wr + 8 * q) = z;
+        }
+        // (only rows below n are stored: a repeated row may find dz where it expects w0 cos -- another wave owns that row)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg_w + rd + 16 * h + 16 * j * kStgLd);
+            if (g * kRows + 32 * wave + (lane >> 2) + 16 * j < a.n) *reinterpret_cast<f32x4*>(gzs + goff[j] + 32 * i + 16 * h) = v;
+          }
+        const float sb = reduce16(Q, lane);  // db_{L-1} += colsum(dz)
+        if (i & 1)
+          g_bl[i >> 1] += pair32(pb, sb);
+        else
+          pb = sb;
+      }
+      park();
+    }
+
+    RP_MARK(0)  // head phase
+    for (int l = n_mm; l >= 1; --l) {
+      const char* mat = a.wtsplit + (int64_t)(l - 1) * split_matrix_bytes(kH);
+      const char* mat_next = l > 1 ? mat - split_matrix_bytes(kH) : mat_top;
+      const float* __restrict__ gd = a.deriv[l - 1];
+      // dz_{l-1} leaves for l - 1 >= 1; for l - 1 = 0 the same stores go to a dummy (the head of this workgroup's slab,
+      // written again at the kernel's end): no branch in the tile loop
+      const bool keep = l - 1 >= 1;
+      float* const zbase = keep ? a.dz[l - 1] : a.partial + (int64_t)blockIdx.x * bwd_slab_floats(kH, L);
+      const int tmul = keep ? 1 : 0;
+      int64_t zoff[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) zoff[j] = keep ? goff[j] : (int64_t)(4 * lane + 256 * j);
+
+      // (only the first region's two fragments here: the other fourteen are split in the gaps of tile 0's MFMAs, a region
+      // ahead of their use -- tile 0 has no epilogue to carry, and the split of all sixteen in front of the tile loop was
+      // 5 k cycles per layer with the matrix pipe idle)
+      x3::Frag cur[kSteps];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = out[ks >> 1][8 * (ks & 1) + j];
+        cur[ks] = x3::split8(v);
+        asm("" : "+a"(cur[ks].h), "+a"(cur[ks].m), "+a"(cur[ks].l));
+      }
+
+      RP_MARK(1)  // the operand's split
+      f32x16 acc[2];
+      x3::Frag wf[2];
+      wf[0] = read_wfrag(ring0 + wslot[0]);
+      f32x4 dv[4];  // w0 cos of the tile whose epilogue is running, a row per lane
+      f32x4 fl[2];  // a half row of dz on its way out
+
+      static_for<kTiles + 1>([&](auto i_c) {  // iteration i: MFMAs of tile i, epilogue of tile i - 1
+        constexpr int i = decltype(i_c)::value;
+        static_for<2>([&](auto hf_c) {
+          constexpr int hf = decltype(hf_c)::value;
+          constexpr int p = 2 * i + hf;
+          static_for<4>([&](auto rg_c) {
+            constexpr int rg = decltype(rg_c)::value;
+            constexpr int ks = kChunkSteps * hf + 2 * rg;
+            constexpr int ti = i > 0 ? i - 1 : 0, pj = 4 * hf + rg, r0 = 2 * pj;
+            constexpr bool mm = i < kTiles, ep = i > 0;
+            constexpr bool first = hf == 0 && rg == 0;
+            constexpr bool next_chunk = rg == 3;
+            constexpr bool have_next = mm && !(next_chunk && p + 1 >= kChunksPerLayer);
+            if constexpr (mm && rg == 3) {
+              // chunk p + 1 has landed for everyone, chunk p - 1's slot is free
+              __builtin_amdgcn_sched_barrier(0);
+              RP_MARK(2)  // MFMAs + epilogue
+              // (what this wave has queued behind chunk p + 1, never fewer: chunk p + 2's six pieces, the four of a
+              // derivative tile, and the two stores of each half-row flush in between)
+              constexpr int younger = 10 + (i >= 2 ? 4 : (i == 1 && hf == 1 ? 2 : 0));
+              if constexpr (younger == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+              if constexpr (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+              if constexpr (younger == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              RP_MARK(3)  // chunk wait + barrier
+            }
+            if constexpr (ep && first) {
+              // the derivative tile of tile i - 1 has landed (queued an iteration ago, twelve or more requests behind it)
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (mm && rg == 3) {
+              constexpr int q = p + 3;
+              issue(q < kChunksPerLayer ? mat : mat_next, (q & (kChunksPerLayer - 1)) >> 1, q & 1, sm.ring[q & 3], wave, lane);
+            }
+            const char* nA = ring0 + wslot[(p + (next_chunk ? 1 : 0)) & 3] + 3 * kPiece * (next_chunk ? 0 : 2 * rg + 2);
+            const char* tB = ring0 + wslot[p & 3] + 3 * kPiece * (2 * rg + 1);
+            static_for<12>([&](auto k_c) {
+              constexpr int k = decltype(k_c)::value;
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (mm) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                constexpr int j = k / 6, t = k % 6, kk = mm ? ks + j : 0;
+                const x3::Frag& w = wf[j];
+                const x3::Frag& v = cur[kk];
+                f32x16& c = acc[i & 1];
+                if constexpr (t == 0) c = mfma(w.h, v.l, first && j == 0 ? zero : c);
+                if constexpr (t == 1) c = mfma(w.l, v.h, c);
+                if constexpr (t == 2) c = mfma(w.m, v.m, c);
+                if constexpr (t == 3) c = mfma(w.h, v.m, c);
+                if constexpr (t == 4) c = mfma(w.m, v.h, c);
+                if constexpr (t == 5) c = mfma(w.h, v.h, c);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (mm && k == 0) wf[1] = read_wfrag(tB);
+              if constexpr (have_next && k == 6) wf[0] = read_wfrag(nA);
+              if constexpr (i == 0 && 2 * pj + 2 < kSteps) {
+                // ---- tile 0: the operand fragments of the NEXT region's two k-steps, a pair of values per gap ----------
+                constexpr int sk = 2 * pj + 2 + (k >> 2 & 1), sq = k & 3;  // gaps 0-3: k-step 2 pj + 2, gaps 4-7: 2 pj + 3
+                if constexpr (k < 8) {
+                  uint32_t h, m, l2;
+                  x3::split2(out[sk >> 1][8 * (sk & 1) + 2 * sq], out[sk >> 1][8 * (sk & 1) + 2 * sq + 1], h, m, l2);
+                  cur[sk].h[sq] = h, cur[sk].m[sq] = m, cur[sk].l[sq] = l2;
+                }
+                if constexpr (k == 8) asm("" : "+a"(cur[2 * pj + 2].h), "+a"(cur[2 * pj + 2].m), "+a"(cur[2 * pj + 2].l));
+                if constexpr (k == 9) asm("" : "+a"(cur[2 * pj + 3].h), "+a"(cur[2 * pj + 3].m), "+a"(cur[2 * pj + 3].l));
+              }
+              // ---- the derivative image: read for tile i - 1 (first region, behind MFMA 2), then -- its bytes are free --
+              // the next tile's four pieces queued (behind MFMA 6)
+              if constexpr (ep && first && k == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dv[q] = *reinterpret_cast<const f32x4*>(din_w + din_rd + 2048 * (q >> 1) + 32 * (q & 1));
+              }
+              if constexpr (mm && first && k == 5) {
+                if constexpr (ep) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // piece e: half e >> 1, rows 16 (e & 1) + (lane >> 2), 16 bytes (lane & 3)
+                  __builtin_amdgcn_global_load_lds(
+                      (const __attribute__((address_space(1))) void*)(gd + goff[e & 1] + 32 * i + 16 * (e >> 1)),
+                      (__attribute__((address_space(3))) void*)(din_w + 1024 * e), 16, 0, 0);
+                }
+              }
+              // ---- the epilogue slice: dz_{l-1} = da (.) w0 cos, accumulator registers 2 pj, 2 pj + 1 (behind MFMA 9)
+              if constexpr (ep && k == 8) {
+                out[ti][r0] = acc[ti & 1][r0] * dv[r0 >> 2][r0 & 3];
+                out[ti][r0 + 1] = acc[ti & 1][r0 + 1] * dv[r0 >> 2][(r0 & 3) + 1];
+              }
+              // ---- the stores, as the forward kernel's: a quad staged a region behind its values, a half row out two
+              // regions later
+              constexpr int qt = pj == 0 ? i - 2 : ti, qq = pj == 0 ? 3 : (pj >> 1) - 1;
+              if constexpr (k == 7 && (pj & 1) == 0 && qt >= 0 && (pj > 0 || i >= 2))
+                *reinterpret_cast<f32x4*>(stg_w + wr + 8 * qq) =
+                    f32x4{out[qt][4 * qq], out[qt][4 * qq + 1], out[qt][4 * qq + 2], out[qt][4 * qq + 3]};
+              constexpr bool f0 = ep && pj == 5, f1 = i >= 2 && pj == 1;
+              constexpr int ft = f0 ? ti : i - 2, fh = f0 ? 0 : 1;
+              if constexpr ((f0 || f1) && k == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fl[j] = *reinterpret_cast<const f32x4*>(stg_w + rd + 16 * fh + 16 * j * kStgLd);
+              }
+              if constexpr ((f0 || f1) && k == 5) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(zbase + zoff[j] + (32 * ft + 16 * fh) * tmul) = fl[j];
+              }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      });
+      RP_MARK(2)
+      {  // the last tile's quad 3 and second half row
+        constexpr int t = kTiles - 1;
+        *reinterpret_cast<f32x4*>(stg_w + wr + 24) = f32x4{out[t][12], out[t][13], out[t][14], out[t][15]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fl[j] = *reinterpret_cast<const f32x4*>(stg_w + rd + 16 + 16 * j * kStgLd);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(zbase + zoff[j] + (32 * t + 16) * tmul) = fl[j];
+      }
+      // ---- bias gradient of sine layer l - 1: column sums of dz_{l-1} over the wave's live rows ----------------------
+      {
+        float pb = 0.f;
+#pragma unroll
+        for (int i = 0; i < kTiles; ++i) {
+          float Q[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Q[r] = live ? out[i][r] : 0.f;
+          const float sb = reduce16(Q, lane);
+          if (i & 1) {
+            const int r = lane & 15, f = 32 * (i - 1 + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + feat0;
+            sm.gb[l - 1][wave][f] += pair32(pb, sb);  // sole owner of (layer, wave, feature)
+          } else {
+            pb = sb;
+          }
+        }
+      }
+    }
+
+    RP_MARK(4)  // tail stores + bias gradient sums
+    // ---- first layer: dW_first[k][d] += sum_rows dz_0[row][k] x[row][d] ----------------------------------------------
+    {
+      float pw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < kTiles; ++i)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          if (d < a.dim_in) {  // (wave-uniform)
+            float P[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[r] = live ? out[i][r] * xv[d] : 0.f;
+            const float sw = reduce16(P, lane);
+            if (i & 1)
+              g_wf[d][i >> 1] += pair32(pw[d], sw);
+            else
+              pw[d] = sw;
+          }
+      park();
+    }
+    RP_MARK(5)  // first layer's weight gradient
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RP_END_TO(g_rows_profile_bwd)
+
+  // ---- this workgroup's slab: dW_head [H] | db_head [4] | db_l [L][H] | dW_first [H][kMaxIn] ---------------------------------
+  // (head weight and head bias: the forward kernel's; zeros here)
+  float* slab = a.partial + (int64_t)blockIdx.x * bwd_slab_floats(kH, L);
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(&sm.ring[0][0]);  // [wave][4 inputs + last bias][H]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = lane & 15, f = 32 * (2 * j + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) red[(wave * 5 + d) * kH + f] = g_wf[d][j];
+    red[(wave * 5 + 4) * kH + f] = g_bl[j];
+  }
+  __syncthreads();
+  {
+    const int f = tid;  // 256 threads = H
+    slab[f] = 0.f;
+    if (f < 4) slab[kH + f] = 0.f;
+    float* p_b = slab + kH + 4;
+    for (int l = 0; l + 1 < L; ++l)
+      p_b[l * kH + f] = ((sm.gb[l][0][f] + sm.gb[l][1][f]) + sm.gb[l][2][f]) + sm.gb[l][3][f];
+    p_b[(L - 1) * kH + f] = ((red[(0 * 5 + 4) * kH + f] + red[(1 * 5 + 4) * kH + f]) + red[(2 * 5 + 4) * kH + f]) + red[(3 * 5 + 4) * kH + f];
+    float* p_wf = p_b + L * kH;
+#pragma unroll
+    for (int d = 0; d < kMaxIn; ++d)
+      p_wf[f * kMaxIn + d] =
+          d < 4 ? ((red[(0 * 5 + d) * kH + f] + red[(1 * 5 + d) * kH + f]) + red[(2 * 5 + d) * kH + f]) + red[(3 * 5 + d) * kH + f]
+                : 0.f;
+  }
+}
+
 }  // namespace rr
 }  // namespace
 
-bool rows_supported(int hidden, int n_sine) { return hidden == rr::kH && n_sine >= 2; }
 int rows_blocks(int64_t n) { return (int)std::min<int64_t>(ceil_div(n, rr::kRows), 256); }
+bool rows_supported(int hidden, int n_sine) { return hidden == rr::kH && n_sine >= 2; }
+// dLoss/dy per row between the loss-mode forward and the backward kernel: behind both kernels' slabs in the slab region
+int64_t rows_dy_offset(int64_t n, int hidden, int n_sine) {
+  const int64_t slabs = (int64_t)rows_blocks(n) * std::max(fwd_slab_floats(hidden), bwd_slab_floats(hidden, n_sine)) * 4;
+  return (slabs + 255) / 256 * 256;
+}
 
 int forward_rows(const ChainArgs& a, int mode, hipStream_t st) {
   const int blocks = rows_blocks(a.n);  // one workgroup per CU
@@ -663,11 +1040,20 @@ int forward_rows(const ChainArgs& a, int mode, hipStream_t st) {
 }
 
 #ifdef SIREN_PROFILE
-extern "C" int mri_debug_set_rows_profile(long long* device_buffer) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(rr::g_rows_profile), &device_buffer, sizeof(device_buffer)) == hipSuccess ? 0 : -1;
+extern "C" int mri_debug_set_rows_profile(long long* device_buffer, int backward) {
+  const hipError_t e = backward ? hipMemcpyToSymbol(HIP_SYMBOL(rr::g_rows_profile_bwd), &device_buffer, sizeof(device_buffer))
+                                : hipMemcpyToSymbol(HIP_SYMBOL(rr::g_rows_profile), &device_buffer, sizeof(device_buffer));
+  return e == hipSuccess ? 0 : -1;
 }
 #endif
 
-int backward_rows(const BwdArgs&, hipStream_t) { return fail(MRI_ERR_INVALID_ARGUMENT, "backward_rows: not built"); }
+bool rows_backward_supported(int hidden, int n_sine, int dim_in, int head_done) {
+  return hidden == rr::kH && n_sine >= 2 && dim_in <= 4 && head_done != 0;
+}
+
+int backward_rows(const BwdArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(rr::siren_backward_rows_kernel, dim3(rows_blocks(a.n)), dim3(rr::kThreadsR), 0, st, a);
+  return check_launch("siren_backward_rows_kernel");
+}
 
 }  // namespace mri

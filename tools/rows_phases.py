@@ -15,28 +15,40 @@ import torch
 from mri_interpolation_amd import _lib, models, trainer
 
 lib = _lib.load()
-train = len(sys.argv) > 1 and sys.argv[1] == "train"
+mode = sys.argv[1] if len(sys.argv) > 1 else "infer"  # infer | train | loss | bwd
+train = mode != "infer"
 net = models.SirenNet(3, 256, 1, 5).cuda()
 st = trainer.FusedStep(net, net.configure_optimizers())
 st.chain_loss = False
 n = 1 << 20
 x = torch.rand(n, 3, device="cuda") * 2 - 1
 buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device="cuda")
-st.forward(x, train=train)
+y = torch.rand(n, 1, device="cuda")
+def run():
+    if mode in ("loss", "bwd"):
+        st._chain_loss_pass(x, y, True, 1.0)
+    else:
+        st.forward(x, train=train)
+if mode in ("loss", "bwd"):
+    st.chain_loss = True
+run()
 torch.cuda.synchronize()
-lib.mri_debug_set_rows_profile.argtypes = [C.c_void_p]
-assert lib.mri_debug_set_rows_profile(C.c_void_p(buf.data_ptr())) == 0
+lib.mri_debug_set_rows_profile.argtypes = [C.c_void_p, C.c_int]
+assert lib.mri_debug_set_rows_profile(C.c_void_p(buf.data_ptr()), 1 if mode == "bwd" else 0) == 0
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
-st.forward(x, train=train)
+run()
 b.record()
 torch.cuda.synchronize()
 t = buf.view(256, 4, 8).double()
 names = ["first layer", "operand split", "MFMAs + interleaved epilogue", "chunk wait + barrier + DMA issue",
-         "last tile's epilogue", "head"]
+         "last tile's epilogue", "head (+ loss tail)"]
+if mode == "bwd":  # (the forward kernel of the pass wrote first; the backward kernel's counters are what is left)
+    names = ["head phase", "operand split", "MFMAs + epilogue", "chunk wait + barrier", "tail stores + bias sums",
+             "first layer's weight gradient"]
 total = t.sum(dim=2).mean()
 groups = n / 128 / 256
-print(f"{'train' if train else 'inference'} forward: {a.elapsed_time(b):.3f} ms with counters; {total:.0f} cycles per wave, "
+print(f"{mode}: {a.elapsed_time(b):.3f} ms with counters; {total:.0f} cycles per wave, "
       f"{total / groups:.0f} per 128-row group (MFMA issue: 4 layers x 768 x 32 = 98304)")
 for i, nm in enumerate(names):
     v = t[:, :, i].mean()
