@@ -63,6 +63,13 @@ __host__ __device__ inline int bwd_slab_floats(int hidden, int n_sine) {
 }
 
 
+struct WgradArgs {
+  const float* dz;    // (n, H)
+  const float* act;   // (n, H): the layer's input
+  int64_t n;
+  float* partial;     // [slabs][H * H]
+};
+
 // siren_rows.hip
 bool rows_supported(int hidden, int n_sine);
 int64_t rows_dy_offset(int64_t n, int hidden, int n_sine);  // bytes into the workspace's slab region

@@ -743,12 +743,6 @@ __global__ __launch_bounds__(256) void siren_bwd_reduce_kernel(const BwdReduceAr
 // Narrow layers have fewer tiles than waves: the waves of one tile then split the chunk's row
 // pairs among themselves and each writes its own slab.  The per-workgroup (per-wave-group)
 // results meet in a slab workspace and are summed in a fixed order (slab_sum_kernel).
-struct WgradArgs {
-  const float* dz;    // (n, H)
-  const float* act;   // (n, H): the layer's input
-  int64_t n;
-  float* partial;     // [gridDim.x * RS][H * H]
-};
 
 template <int HH>
 struct WgradShape {
