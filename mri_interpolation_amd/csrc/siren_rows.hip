@@ -258,6 +258,10 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
 #pragma unroll
       for (int j = 0; j < 2; ++j) v[j] = *reinterpret_cast<const f32x4*>(stg_w + arr * 32 * kStgLd + rd + 16 * h + 16 * j * kStgLd);
     };
+    auto put_a = [&](float* base, const int64_t (&off)[2], int mul, int tile, int h, const f32x4 (&v)[2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(base + off[j] + (32 * tile + 16 * h) * mul) = v[j];
+    };
     auto put = [&](float* base, int tile, int h, const f32x4 (&v)[2]) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(base + goff[j] + 32 * tile + 16 * h) = v[j];
@@ -325,13 +329,17 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
     for (int l = 1; l <= n_mm; ++l) {
       const char* mat = a.wsplit + (int64_t)(l - 1) * split_matrix_bytes(kH);
       const char* mat_next = l < n_mm ? mat + split_matrix_bytes(kH) : a.wsplit;
-      // The last sine layer of the loss mode: a stays on chip, w0 cos waits in dz_last.  Its a is stored all the same -- into
-      // dz_last, a slice ahead of the w0 cos that overwrites it: a wave-uniform branch around those stores would cut the
-      // regions below into blocks, and the compiler then sinks the range check's running maximum behind them, keeping
-      // (spilling) every slice's arguments until the tile's end.
+      // The last sine layer of the loss mode: a stays on chip, w0 cos waits in dz_last.  Its a is "stored" all the same --
+      // into 2 KB of this workgroup's slab (written for good at the kernel's end), every tile to the same bytes: a
+      // wave-uniform branch around those stores would cut the regions below into blocks, and the compiler then sinks the
+      // range check's running maximum behind them, keeping (spilling) every slice's arguments until the tile's end.
       const bool keep_a = LOSS && l == n_mm;
       float* gd = STORE ? (keep_a ? a.dz_last : a.deriv[l]) : nullptr;
-      float* ga = STORE ? (keep_a ? a.dz_last : a.act[l]) : nullptr;
+      float* ga = STORE ? (keep_a ? a.partial + (int64_t)blockIdx.x * fwd_slab_floats(kH) : a.act[l]) : nullptr;
+      const int amul = keep_a ? 0 : 1;
+      int64_t aoff[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) aoff[j] = keep_a ? (int64_t)(4 * lane + 256 * j) : goff[j];
       const float w0 = a.w0;
 
       // the layer's operand: k-step ks contracts features 16 ks + 4 lh + (j & 3) + 8 (j >> 2) = registers 8 (ks & 1) + j of tile ks / 2
@@ -445,7 +453,9 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               if constexpr (n == 21) nx = (qx & 2) == 0, ny = (qy & 2) == 0;
               if constexpr (n == 22) ax = ex ? snx : csx, ay = ey ? sny : csy;
               if constexpr (n == 23) sx = nx ? ax : -ax, sy = ny ? ay : -ay;
-              if constexpr (n == 25) smax = fmaxf(smax, fmaxf(fabsf(sx), fabsf(sy)));  // (a use in front of the range check: nothing sinks behind it)
+              // (a use in front of the range check: nothing sinks behind its branch.  Of the SIGNED values: |s| does not need
+              // the quadrant's sign, and the inference form then kept -- spilled -- sign bits and magnitudes for later)
+              if constexpr (n == 25) smax = fmaxf(smax, fmaxf(sx, sy));
               if constexpr (n == 24) out[ti][r0] = sx, out[ti][r0 + 1] = sy;
               // (26: a spare slot of the inference form)
               if constexpr (n == 27) ax = ex ? csx : snx, ay = ey ? csy : sny;
@@ -496,7 +506,12 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
                 constexpr bool f0 = ep && (pj == 5 || pj == 6), f1 = i >= 2 && (pj == 1 || pj == 2);
                 constexpr int ft = f0 ? ti : i - 2, fh = f0 ? 0 : 1, fa = (pj == 5 || pj == 1) ? 0 : 1;
                 if constexpr ((f0 || f1) && k == 1) unstage(fa, fh, fl);
-                if constexpr ((f0 || f1) && k == 5) put(fa ? gd : ga, ft, fh, fl);
+                if constexpr ((f0 || f1) && k == 5) {
+                  if constexpr (fa)
+                    put(gd, ft, fh, fl);
+                  else
+                    put_a(ga, aoff, amul, ft, fh, fl);
+                }
               }
               if constexpr (mm && k == 0) wf[1] = read_wfrag(tB);
               if constexpr (have_next && k == 6) wf[0] = read_wfrag(nA);
@@ -546,8 +561,9 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               for (int r = 0; r < 16; ++r) dq[r] = w0 * fix[(16 + r) * 64 + lane];
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                *reinterpret_cast<f32x4*>(ga + row * kH + feat0 + 32 * ti + 8 * q) =
-                    f32x4{out[ti][4 * q], out[ti][4 * q + 1], out[ti][4 * q + 2], out[ti][4 * q + 3]};
+                if (!keep_a)
+                  *reinterpret_cast<f32x4*>(ga + row * kH + feat0 + 32 * ti + 8 * q) =
+                      f32x4{out[ti][4 * q], out[ti][4 * q + 1], out[ti][4 * q + 2], out[ti][4 * q + 3]};
                 *reinterpret_cast<f32x4*>(gd + row * kH + feat0 + 32 * ti + 8 * q) =
                     f32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]};
               }
@@ -567,7 +583,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
         stage(1, 3, f32x4{dd[0], dd[1], dd[2], dd[3]});
         f32x4 va[2], vd[2];
         unstage(0, 1, va), unstage(1, 1, vd);
-        put(ga, t, 1, va), put(gd, t, 1, vd);
+        put_a(ga, aoff, amul, t, 1, va), put(gd, t, 1, vd);
       }
     }
 
