@@ -339,8 +339,10 @@ int mri_tiny_mlp_train_overlapped(const float* x, const float* target, int64_t n
 /* ---- fused SIREN chain -------------------------------------------------------------------
  * SirenNet.forward (reference models.py:230-233): n_sine_layers x [F.linear -> sin(w0 .)]
  * (SirenLayer.forward, models.py:153-156; the first layer with w0_first) and the linear head,
- * in ONE persistent kernel: a 64-row tile's activations stay in LDS across all layers, the
- * hidden x hidden weights stream from L2 (csrc/siren_chain.hip).  Supported: hidden in
+ * in ONE persistent kernel: a row tile's activations stay on chip across all layers -- in the
+ * registers of the wave that owns the rows at hidden = 256 (csrc/siren_rows.hip), in an LDS image
+ * at the other widths (csrc/siren_chain.hip) --, the hidden x hidden weights stream from L2.
+ * Supported: hidden in
  * {32, 64, 128, 256}, dim_in <= 8, 1 <= n_sine_layers <= MRI_SIREN_MAX_LAYERS, one output, biases everywhere
  * (mri_siren_supported); other shapes go layer by layer through mri_linear_*.
  * weight / bias: HOST arrays of n_sine_layers + 1 device pointers -- [0] (hidden, dim_in),
@@ -367,7 +369,10 @@ int mri_siren_forward(const float* x, int64_t n, int32_t dim_in, int32_t hidden,
  * reproducible).  act / deriv: what mri_siren_forward stored; dz: HOST array of n_sine_layers
  * device pointers to (n, hidden) scratch ([0] unused, may be NULL); d_weight / d_bias: HOST arrays
  * of n_sine_layers + 1 device pointers, gradients are ADDED to them.  head_done = 1: the head's
- * backward was done by mri_siren_forward_loss (dy, act / deriv [n_sine_layers - 1] unused). */
+ * backward was done by mri_siren_forward_loss (dy, act / deriv [n_sine_layers - 1] unused).
+ * head_done = 1 continues THAT call: same n, same network, the SAME `workspace` bytes, untouched in
+ * between, and the same "siren_rows" option -- at hidden = 256 the two calls share the work of the head
+ * (what the forward call leaves in dz[n_sine_layers - 1] and in the workspace is private to the pair). */
 int64_t mri_siren_backward_workspace_bytes(int64_t n, int32_t hidden, int32_t n_sine_layers);
 int mri_siren_backward(const float* x, const float* dy, int64_t n, int32_t dim_in, int32_t hidden,
                        int32_t n_sine_layers, const float* const* weight,

@@ -97,8 +97,10 @@ for name in ("cfg4", "cfg4_packed", "cfg2", "cfg5"):
                "hashgrid_fwd": int(next(v for k, v in t4.items() if k.startswith("hashgrid_fwd")) * 1e6),
                "adam": int(t4["adam_kernel"] * 1e6)}
 split = t3.get("siren_split_weights_kernel", 0) / 2  # launched by the forward and by the backward entry
-d["cfg3"] = {"mlp_fwd": int((t3["siren_forward_kernel"] + t3.get("siren_fwd_reduce_kernel", 0) + split) * 1e6),
-             "mlp_bwd": int((t3["siren_backward_kernel"] + t3.get("siren_bwd_reduce_kernel", 0) + split +
+fwd3 = next(v for k, v in t3.items() if k.startswith("siren_forward"))    # siren_forward_rows_kernel (H = 256) / siren_forward_kernel
+bwd3 = next(v for k, v in t3.items() if k.startswith("siren_backward"))
+d["cfg3"] = {"mlp_fwd": int((fwd3 + t3.get("siren_fwd_reduce_kernel", 0) + split) * 1e6),
+             "mlp_bwd": int((bwd3 + t3.get("siren_bwd_reduce_kernel", 0) + split +
                              4 * (t3["siren_wgrad_kernel"] + t3.get("slab_sum_kernel", 0))) * 1e6),
              "adam": int(t3["adam_kernel"] * 1e6)}
 json.dump(d, open(tj, "w"), indent=2)
