@@ -1142,6 +1142,20 @@ extern "C" int64_t mri_siren_forward_workspace_bytes(int32_t hidden, int32_t n_s
   return split_region_bytes(hidden, n_sine_layers);
 }
 
+namespace mri {
+namespace {
+// What the last mri_siren_forward_loss of this host thread left behind: mri_siren_backward(head_done = 1) continues exactly
+// that call (the two kernel families park different things in dz_last and the workspace), so it checks instead of trusting.
+struct LossCall {
+  const void* workspace = nullptr;
+  const void* dz_last = nullptr;
+  int64_t n = -1;
+  int hidden = 0, n_sine = 0, rows = -1;
+};
+thread_local LossCall g_last_loss_call;
+}  // namespace
+}  // namespace mri
+
 extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64_t n,
                                       int64_t n_total, int32_t dim_in, int32_t hidden,
                                       int32_t n_sine_layers, const float* const* weight,
@@ -1182,6 +1196,8 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   }
   hipStream_t st = (hipStream_t)stream;
   a.wsplit = wsplit;
+  g_last_loss_call = LossCall{workspace, dz_last, n, hidden, n_sine_layers,
+                              options().siren_rows && rows_backward_supported(hidden, n_sine_layers, dim_in, 1) ? 1 : 0};
   if (int rc = split_weights(weight, n_sine_layers, hidden, false, wsplit, st)) return rc;
   if (int rc = forward_any(hidden, a, 2, st)) return rc;
   FwdReduceArgs r{};
@@ -1258,6 +1274,15 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   a.wtsplit = wtsplit;
   if (int rc = split_weights(weight, L, hidden, true, wtsplit, st)) return rc;
   const bool rows = options().siren_rows && rows_backward_supported(hidden, L, dim_in, head_done);
+  if (head_done) {
+    const LossCall& c = g_last_loss_call;
+    MRI_REQUIRE(c.workspace == workspace && c.dz_last == dz[L - 1] && c.n == n && c.hidden == hidden && c.n_sine == L &&
+                    c.rows == (rows ? 1 : 0),
+                "mri_siren_backward(head_done = 1) continues the mri_siren_forward_loss call before it: same n, network, "
+                "dz[n_sine_layers - 1] = dz_last, workspace and \"siren_rows\" option (got n %lld / %lld, hidden %d / %d, "
+                "layers %d / %d, rows kernels %d / %d)", (long long)n, (long long)c.n, hidden, c.hidden, L, c.n_sine,
+                rows ? 1 : 0, c.rows);
+  }
   if (int rc = rows ? backward_rows(a, st) : backward_any(hidden, a, st)) return rc;
   BwdReduceArgs r{};
   r.partial = a.partial, r.slabs = rows ? rows_blocks(n) : chain_blocks(hidden, n), r.hidden = hidden, r.n_sine = L;

@@ -132,3 +132,30 @@ def test_rows_sincos_cold_path(amd, where):
         assert_close(grad.cpu().numpy(), grad0.cpu().numpy(), 2e-6, "gradients vs image kernels")
     finally:
         assert lib.mri_set_option(b"siren_rows", 1) == 0
+
+
+def test_head_done_checks_what_it_continues(amd, monkeypatch):
+    """mri_siren_backward(head_done = 1) continues the mri_siren_forward_loss call before it (at width 256 the forward
+    call parks w0 cos in dz_last and dLoss/dy in the workspace): a backward call that does not match -- another kernel
+    family selected in between, another batch size -- fails loudly instead of reading the wrong thing."""
+    from mri_interpolation_amd import ops
+    lib = amd.lib.load()
+    net, _ = _net(amd, 3, 3, 5)
+    x = torch.rand(500, 3, device="cuda") * 2 - 1
+    y = torch.rand(500, 1, device="cuda")
+    st = amd.trainer.FusedStep(net, net.configure_optimizers())
+    real_backward = ops.siren_backward
+
+    def flipped(*args, **kw):
+        assert lib.mri_set_option(b"siren_rows", 0) == 0
+        try:
+            return real_backward(*args, **kw)
+        finally:
+            assert lib.mri_set_option(b"siren_rows", 1) == 0
+
+    monkeypatch.setattr(ops, "siren_backward", flipped)
+    with pytest.raises(RuntimeError, match="continues the mri_siren_forward_loss call"):
+        st._chain_loss_pass(x, y, True, 1.0)
+    monkeypatch.setattr(ops, "siren_backward", real_backward)
+    st._chain_loss_pass(x, y, True, 1.0)  # the matching pair still works
+    assert torch.isfinite(st.flat.grad).all()
