@@ -17,14 +17,22 @@
 //     by the lane that computed it, and is never written to LDS;
 //   * one workgroup = 4 waves, one per SIMD, 128 rows; a wave owns its 32 rows through the whole chain (up to 512
 //     registers per lane: 192 for the layer's split input, 128 for its f32 output, 32 for two accumulator tiles);
-//   * LDS holds nothing but a ring of weight chunks (4 x 24 KB; a chunk = the 32 features of one output tile x
-//     128 contraction indices x three terms) filled by LDS-DMA three chunks ahead; the matrix is streamed once per
-//     128 rows (half the L2 traffic per row), one workgroup barrier per chunk = per 48 MFMAs of a wave, placed
-//     two k-steps before the chunk's end so that the next chunk's first fragments are requested early;
-//   * the sincos epilogue of output tile i runs beside the MFMAs of tile i + 1 IN THE SAME WAVE: the order
-//     (one MFMA, a few vector instructions, ...) is fixed by __builtin_amdgcn_sched_group_barrier.  The branch
-//     of sincos_fast2 (|u| > 8192 -> library sincosf) would cut those scheduling regions: the interleaved code is
-//     branch-free, the range is checked once per tile and out-of-range values are repaired on a cold path.
+//   * LDS holds a ring of weight chunks (4 x 24 KB; a chunk = the 32 features of one output tile x 128 contraction
+//     indices x three terms) filled by LDS-DMA three chunks ahead, the small parameters and a 9 KB staging image
+//     per wave; the matrix is streamed once per 128 rows (half the L2 traffic per row), one workgroup barrier per
+//     chunk = per 48 MFMAs of a wave, placed two k-steps before the chunk's end so that the next chunk's first
+//     fragments are requested early;
+//   * the sincos epilogue of output tile i runs beside the MFMAs of tile i + 1 IN THE SAME WAVE: the order (one
+//     MFMA, five or six vector instructions, ...) is written out gap by gap between sched_barrier(0) fences (a
+//     sched_group_barrier pipeline is dropped by the scheduler when it judges the interleaved order's register
+//     pressure too high).  The branch of sincos_fast2 (|u| > 8192 -> library sincosf) would cut those regions:
+//     the interleaved code is branch-free, the range is checked once per tile and out-of-range values are
+//     repaired on a cold path;
+//   * a lane owns a ROW, 1 KB apart in HBM from its neighbours': activations leave (and the backward kernel's
+//     derivative tiles arrive) through per-wave LDS images, transposed to 4 lanes x 16 bytes per half row;
+//   * the backward chain (siren_backward_rows_kernel, below) has the same ownership from the head down; the
+//     loss-mode forward leaves it w0 cos of the last sine layer and dLoss/dy per row.
+// DESIGN.md 4.5 has the cycle budget; EXPERIMENTS.md (Part I) what the compiler needed to get there.
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
           constexpr int p = 2 * i + hf;  // chunk of the layer
           static_for<4>([&](auto rg_c) {
             constexpr int rg = decltype(rg_c)::value;
-            constexpr int ks = kChunkSteps * hf + 2 * rg;  // this region's k-steps: ks (accA), ks + 1 (accB)
+            constexpr int ks = kChunkSteps * hf + 2 * rg;  // this region's k-steps: ks, ks + 1
             if constexpr (i < kTiles && rg == 3) {
               // ---- chunk p + 1 has landed for everyone, chunk p - 1's slot is free (chunk p + 3 goes there, below) ----
               __builtin_amdgcn_sched_barrier(0);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where a wave of the fused SIREN forward kernel spends its cycles (tools-only profile build).
+"""Where a wave of the LDS-image SIREN forward kernel (csrc/siren_chain.hip) spends its cycles (tools-only profile build;
+for the rows kernels of width 256 see tools/rows_phases.py).
 
     python tools/build_variant.py --name=libmri_sprof.so -DSIREN_PROFILE     # here
     MRI_LIB=tools/libmri_sprof.so python tools/siren_phases.py [train]      # on the GPU box
@@ -14,6 +15,7 @@ import torch
 from mri_interpolation_amd import _lib, models, ops, trainer
 
 lib = _lib.load()
+lib.mri_set_option(b"siren_rows", 0)  # the LDS-image kernel (csrc/siren_chain.hip); the rows kernels: tools/rows_phases.py
 train = len(sys.argv) > 1 and sys.argv[1] == "train"
 net = models.SirenNet(3, 256, 1, 5).cuda()
 st = trainer.FusedStep(net, net.configure_optimizers())
