@@ -148,14 +148,23 @@ __device__ __forceinline__ float dpp(float v) {
 }
 __device__ __forceinline__ float reduce16(const float (&v)[16], int lane) {
   const bool u1 = (lane & 1) != 0, u2 = (lane & 2) != 0, u4 = (lane & 4) != 0, u8 = (lane & 8) != 0;
-  float a8[8], a4[4], a2[2];
+  // (per level: every select first, then the exchanges -- a DPP operand written by the instruction in front of it costs
+  // two wait states)
+  float k8[8], s8[8], a8[8], k4[4], s4[4], a4[4], k2[2], s2[2], a2[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a8[j] = (u1 ? v[2 * j + 1] : v[2 * j]) + dpp<0xB1>(u1 ? v[2 * j] : v[2 * j + 1]);
+  for (int j = 0; j < 8; ++j) k8[j] = u1 ? v[2 * j + 1] : v[2 * j], s8[j] = u1 ? v[2 * j] : v[2 * j + 1];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) a4[j] = (u2 ? a8[2 * j + 1] : a8[2 * j]) + dpp<0x4E>(u2 ? a8[2 * j] : a8[2 * j + 1]);
+  for (int j = 0; j < 8; ++j) a8[j] = k8[j] + dpp<0xB1>(s8[j]);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) a2[j] = (u4 ? a4[2 * j + 1] : a4[2 * j]) + dpp<0x1B>(dpp<0x141>(u4 ? a4[2 * j] : a4[2 * j + 1]));
-  return (u8 ? a2[1] : a2[0]) + dpp<0x141>(dpp<0x140>(u8 ? a2[0] : a2[1]));
+  for (int j = 0; j < 4; ++j) k4[j] = u2 ? a8[2 * j + 1] : a8[2 * j], s4[j] = u2 ? a8[2 * j] : a8[2 * j + 1];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a4[j] = k4[j] + dpp<0x4E>(s4[j]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) k2[j] = u4 ? a4[2 * j + 1] : a4[2 * j], s2[j] = dpp<0x141>(u4 ? a4[2 * j] : a4[2 * j + 1]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) a2[j] = k2[j] + dpp<0x1B>(s2[j]);
+  const float k1 = u8 ? a2[1] : a2[0], s1 = dpp<0x140>(u8 ? a2[0] : a2[1]);
+  return k1 + dpp<0x141>(s1);
 }
 // ... and over bit 4 of the lane for a pair of tiles: lanes with the bit clear end up with the even tile's sum over the
 // wave's 32 rows, the others with the odd tile's (v_permlane16_swap exchanges the odd rows of one register with the even
@@ -967,19 +976,13 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
       }
       // ---- bias gradient of sine layer l - 1: column sums of dz_{l-1} over the wave's live rows ----------------------
       {
-        float pb = 0.f;
 #pragma unroll
-        for (int i = 0; i < kTiles; ++i) {
-          float Q[16];
+        for (int j = 0; j < kTiles / 2; ++j) {
+          float Qa[16], Qb[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Q[r] = live ? out[i][r] : 0.f;
-          const float sb = reduce16(Q, lane);
-          if (i & 1) {
-            const int r = lane & 15, f = 32 * (i - 1 + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + feat0;
-            sm.gb[l - 1][wave][f] += pair32(pb, sb);  // sole owner of (layer, wave, feature)
-          } else {
-            pb = sb;
-          }
+          for (int r = 0; r < 16; ++r) Qa[r] = live ? out[2 * j][r] : 0.f, Qb[r] = live ? out[2 * j + 1][r] : 0.f;
+          const int r = lane & 15, f = 32 * (2 * j + ((lane >> 4) & 1)) + (r & 3) + 8 * (r >> 2) + feat0;
+          sm.gb[l - 1][wave][f] += pair32(reduce16(Qa, lane), reduce16(Qb, lane));  // sole owner of (layer, wave, feature)
         }
       }
     }
@@ -987,21 +990,19 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
     RP_MARK(4)  // tail stores + bias gradient sums
     // ---- first layer: dW_first[k][d] += sum_rows dz_0[row][k] x[row][d] ----------------------------------------------
     {
-      float pw[4] = {0.f, 0.f, 0.f, 0.f};
+      // (inputs beyond dim_in are zeros: the first three always, the fourth behind ONE wave-uniform branch -- a branch per
+      // butterfly kept the compiler from interleaving the independent ones, and a DPP chain alone is mostly wait states)
+      auto input = [&](int d) {
 #pragma unroll
-      for (int i = 0; i < kTiles; ++i)
+        for (int j = 0; j < kTiles / 2; ++j) {
+          float Pa[16], Pb[16];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          if (d < a.dim_in) {  // (wave-uniform)
-            float P[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) P[r] = live ? out[i][r] * xv[d] : 0.f;
-            const float sw = reduce16(P, lane);
-            if (i & 1)
-              g_wf[d][i >> 1] += pair32(pw[d], sw);
-            else
-              pw[d] = sw;
-          }
+          for (int r = 0; r < 16; ++r) Pa[r] = live ? out[2 * j][r] * xv[d] : 0.f, Pb[r] = live ? out[2 * j + 1][r] * xv[d] : 0.f;
+          g_wf[d][j] += pair32(reduce16(Pa, lane), reduce16(Pb, lane));
+        }
+      };
+      input(0), input(1), input(2);
+      if (a.dim_in > 3) input(3);
       park();
     }
     RP_MARK(5)  // first layer's weight gradient
