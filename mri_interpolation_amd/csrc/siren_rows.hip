@@ -746,6 +746,32 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
   const int wr = l31 * kStgLd + feat0, rd = (lane >> 2) * kStgLd + 4 * (lane & 3);
   const int din_rd = (l31 >> 4) * 1024 + (l31 & 15) * 64 + 16 * lh;  // + 2048 (q >> 1) + 32 (q & 1)
 
+  // A group's first requests -- its rows' dLoss/dy and x, the first two tiles of w0 cos of the last sine layer (by LDS-DMA
+  // into this wave's derivative image and its share of ring slot 3) -- are made a phase ahead: for the first group here, for
+  // the others in front of the previous group's first-layer phase, when both images are free.  (Made at the group's own
+  // start they cost a full round trip each, the dy load behind a vmcnt(0) that also drains the previous group's stores.)
+  float dy_pre = 0.f, x_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  char* const buf1 = &sm.ring[3][0] + 4096 * wave;
+  auto fetch_tile = [&](const int64_t (&off)[2], int i) {
+    char* dst = (i & 1) ? buf1 : din_w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(a.dz[n_mm] + off[e & 1] + 32 * i + 16 * (e >> 1)),
+          (__attribute__((address_space(3))) void*)(dst + 1024 * e), 16, 0, 0);
+  };
+  auto prefetch = [&](int64_t g) {
+    const int64_t row = std::min<int64_t>(g * kRows + 32 * wave + l31, a.n - 1);
+    dy_pre = a.dy_ws[row];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) x_pre[d] = d < a.dim_in ? a.x[row * a.dim_in + d] : 0.f;
+    int64_t off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      off[j] = std::min<int64_t>(g * kRows + 32 * wave + (lane >> 2) + 16 * j, a.n - 1) * kH + 4 * (lane & 3);
+    fetch_tile(off, 0), fetch_tile(off, 1);
+  };
+  if ((int64_t)blockIdx.x < groups) prefetch(blockIdx.x);
   RP_BEGIN
   for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const int64_t row = std::min<int64_t>(g * kRows + 32 * wave + l31, a.n - 1);
@@ -756,26 +782,17 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
       goff[j] = std::min<int64_t>(g * kRows + 32 * wave + (lane >> 2) + 16 * j, a.n - 1) * kH + 4 * (lane & 3);
     float xv[4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) xv[d] = d < a.dim_in ? a.x[row * a.dim_in + d] : 0.f;
+    for (int d = 0; d < 4; ++d) xv[d] = x_pre[d];
 
     // ---- the head: dz_{L-1} = dy w_head (.) w0 cos.  The loss-mode forward kernel left w0 cos of the last sine layer
     // in dz[L-1] and dLoss/dy in the workspace; the tiles come in by LDS-DMA, two in flight (this wave's derivative
-    // image and its share of ring slot 3, free until the group's first chunk sync), and leave as dz the way they came.
+    // image and its share of ring slot 3, free until the group's first chunk sync; the first two were queued a phase ago),
+    // and leave as dz the way they came.
     float out[kTiles][16];
     {
-      const float dyv = a.dy_ws[row];
+      const float dyv = dy_pre;  // (its wait also covers the two tiles queued with it: a phase old by now)
       float* const gzs = a.dz[n_mm];
-      char* const buf1 = &sm.ring[3][0] + 4096 * wave;
-      auto fetch = [&](int i) {
-        char* dst = (i & 1) ? buf1 : din_w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(gzs + goff[e & 1] + 32 * i + 16 * (e >> 1)),
-              (__attribute__((address_space(3))) void*)(dst + 1024 * e), 16, 0, 0);
-      };
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dy_ws[row] is in its register: every count below starts from nothing)
-      fetch(0), fetch(1);
+      auto fetch = [&](int i) { fetch_tile(goff, i); };
       float pb = 0.f;
 #pragma unroll
       for (int i = 0; i < kTiles; ++i) {
@@ -988,6 +1005,12 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
     }
 
     RP_MARK(4)  // tail stores + bias gradient sums
+    if (g + gridDim.x < groups) {  // (workgroup-uniform)
+      // ring slot 3 held the layer's last chunk: every wave is done reading it behind this barrier (one per group); the
+      // wave's own derivative image is free since its last tile was read
+      __builtin_amdgcn_s_barrier();
+      prefetch(g + gridDim.x);
+    }
     // ---- first layer: dW_first[k][d] += sum_rows dz_0[row][k] x[row][d] ----------------------------------------------
     {
       // (inputs beyond dim_in are zeros: the first three always, the fourth behind ONE wave-uniform branch -- a branch per
