@@ -75,6 +75,10 @@ struct Smem {
   // instruction measured).  Through this image the pieces go out as the rows lie: 4 lanes per 64-byte half row.  The cold
   // path (arguments beyond the fast sincos' range) borrows the same bytes as [value][lane].
   float stg[4][2][32 * kStgLd];
+  // Per wave: a group's coordinates (one row of 64 lanes per input) and, by group parity, its targets: requested by
+  // LDS-DMA a whole group ahead.  (Loaded into registers at the group's start they sit behind a wait that hipcc makes
+  // vmcnt(0) -- an LDS-DMA is always in flight -- i.e. behind the previous group's last stores.)
+  float xin[4][kMaxIn + 2][64];
   char ring[kRing][kChunk] __attribute__((aligned(16)));
 };
 
@@ -82,17 +86,8 @@ __device__ __forceinline__ f32x16 mfma(const x3::u32x4& a, const x3::u32x4& b, f
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3::bf16x8, a),
                                                  __builtin_bit_cast(x3::bf16x8, b), c, 0, 0, 0);
 }
-// acc += W_frag (32 features x 16 k) * act_frag (16 k x 32 rows): the six products of siren_chain.hip's mma6_32
-// (activation term x weight term: l h, h l, m m, m h, h m, h h), smallest first
-__device__ __forceinline__ f32x16 kstep(const x3::Frag& w, const x3::Frag& v, f32x16 c) {
-  c = mfma(w.h, v.l, c);
-  c = mfma(w.l, v.h, c);
-  c = mfma(w.m, v.m, c);
-  c = mfma(w.h, v.m, c);
-  c = mfma(w.m, v.h, c);
-  c = mfma(w.h, v.h, c);
-  return c;
-}
+// (a k-step = six of these, weight term x activation term: h l, l h, m m, h m, m h, h h -- the six products of
+// siren_chain.hip's mma6_32, smallest first; written out in the tile loops)
 
 // Queue this wave's share (6 of the 24 one-KiB pieces) of chunk (tile, half) of one split matrix: piece pc =
 // k-step pc / 3 of the half, term plane pc % 3; lane = 16-byte slot, fetched with the half bit XORed by bit 3 of
@@ -113,17 +108,6 @@ __device__ __forceinline__ x3::Frag read_wfrag(const char* __restrict__ p) {
   f.m = *reinterpret_cast<const x3::u32x4*>(p + kPiece);
   f.l = *reinterpret_cast<const x3::u32x4*>(p + 2 * kPiece);
   return f;
-}
-
-// one MFMA, then `V` vector instructions, six times; then the three fragment reads of a k-step
-template <int V>
-__device__ __forceinline__ void sched_kstep() {
-#pragma unroll
-  for (int m = 0; m < 6; ++m) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-  }
-  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 }
 
 // Loops whose index must be a compile-time constant (register arrays, scheduling fences): `#pragma unroll` is a
@@ -238,8 +222,19 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
   const char* const ring0 = &sm.ring[0][0];
   const int feat0 = 4 * lh;  // feature of accumulator register r of tile i: 32 i + (r & 3) + 8 (r >> 2) + feat0
 
+  // a group's coordinates (and targets, slot kMaxIn + parity) on their way into xin: 4 bytes per lane and input
+  auto request = [&](int64_t gg, int parity) {
+    const int64_t r = std::min<int64_t>(gg * kRows + 32 * wave + l31, a.n - 1);
+    for (int d = 0; d < a.dim_in; ++d)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + r * a.dim_in + d),
+                                       (__attribute__((address_space(3))) void*)&sm.xin[wave][d][0], 4, 0, 0);
+    if constexpr (LOSS)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.target + r),
+                                       (__attribute__((address_space(3))) void*)&sm.xin[wave][kMaxIn + parity][0], 4, 0, 0);
+  };
   // the chunk stream: chunks 0, 1, 2 of the first group
   if ((int64_t)blockIdx.x < groups) {
+    request(blockIdx.x, 0);
     issue(a.wsplit, 0, 0, sm.ring[0], wave, lane);
     issue(a.wsplit, 0, 1, sm.ring[1], wave, lane);
     issue(a.wsplit, 1, 0, sm.ring[2], wave, lane);
@@ -258,7 +253,8 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
   };
   park();
   RP_BEGIN
-  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+  int gpar = 0;  // parity of this workgroup's group count: which target slot is this group's
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x, gpar ^= 1) {
     // rows beyond n repeat row n - 1: the same values to the same addresses, no exec-masked store (a divergent branch
     // would cut the scheduling regions below)
     const int64_t row = std::min<int64_t>(g * kRows + 32 * wave + l31, a.n - 1);
@@ -266,18 +262,17 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
     // staging (STORE): this lane writes quad q of its row at wr + 8 q, reads piece (lane & 3) of rows (lane >> 2) + 16 j
     float* const stg_w = &sm.stg[wave][0][0];
     const int wr = l31 * kStgLd + feat0, rd = (lane >> 2) * kStgLd + 4 * (lane & 3);
-    int64_t goff[2];  // element offsets of those two rows' pieces in an (n, H) array
+    // element offsets of those two rows' pieces in an (n, H) array, from the group's first row (32 bits per lane; the
+    // group's base is wave-uniform: two 64-bit offsets per lane were the registers the loss mode did not have)
+    const int64_t gbase = g * kRows * kH;
+    int goff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      goff[j] = std::min<int64_t>(g * kRows + 32 * wave + (lane >> 2) + 16 * j, a.n - 1) * kH + 4 * (lane & 3);
+      goff[j] = (int)std::min<int64_t>(32 * wave + (lane >> 2) + 16 * j, a.n - 1 - g * kRows) * kH + 4 * (lane & 3);
     auto stage = [&](int arr, int q, const f32x4& v) { *reinterpret_cast<f32x4*>(stg_w + arr * 32 * kStgLd + wr + 8 * q) = v; };
     auto unstage = [&](int arr, int h, f32x4 (&v)[2]) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) v[j] = *reinterpret_cast<const f32x4*>(stg_w + arr * 32 * kStgLd + rd + 16 * h + 16 * j * kStgLd);
-    };
-    auto put_a = [&](float* base, const int64_t (&off)[2], int mul, int tile, int h, const f32x4 (&v)[2]) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(base + off[j] + (32 * tile + 16 * h) * mul) = v[j];
     };
     auto put = [&](float* base, int tile, int h, const f32x4 (&v)[2]) {
 #pragma unroll
@@ -286,9 +281,14 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
 
     // ---- first layer on the VALU (K = dim_in) -----------------------------------------------------------
     {
+      // this group's coordinates were requested a group ago (the first group's in the prologue): more than 63 requests
+      // lie behind them in this wave's queue
+      asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
       float xv[kMaxIn];
 #pragma unroll
-      for (int d = 0; d < kMaxIn; ++d) xv[d] = d < a.dim_in ? a.x[row * a.dim_in + d] : 0.f;
+      for (int d = 0; d < kMaxIn; ++d) xv[d] = d < a.dim_in ? sm.xin[wave][d][lane] : 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read: the next group's may land
+      if (g + gridDim.x < groups) request(g + gridDim.x, gpar ^ 1);
       const bool wide = a.dim_in > 4;
 #pragma unroll
       for (int i = 0; i < kTiles; ++i) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
           for (int h = 0; h < 2; ++h) {
             f32x4 va[2], vd[2];
             unstage(0, h, va), unstage(1, h, vd);
-            put(a.act[0], i, h, va), put(a.deriv[0], i, h, vd);
+            put(a.act[0] + gbase, i, h, va), put(a.deriv[0] + gbase, i, h, vd);
           }
         }
       }
@@ -346,17 +346,14 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
     for (int l = 1; l <= n_mm; ++l) {
       const char* mat = a.wsplit + (int64_t)(l - 1) * split_matrix_bytes(kH);
       const char* mat_next = l < n_mm ? mat + split_matrix_bytes(kH) : a.wsplit;
-      // The last sine layer of the loss mode: a stays on chip, w0 cos waits in dz_last.  Its a is "stored" all the same --
-      // into 2 KB of this workgroup's slab (written for good at the kernel's end), every tile to the same bytes: a
-      // wave-uniform branch around those stores would cut the regions below into blocks, and the compiler then sinks the
-      // range check's running maximum behind them, keeping (spilling) every slice's arguments until the tile's end.
+      // The last sine layer of the loss mode: a stays on chip, w0 cos waits in dz_last.  Its a is stored all the same -- into
+      // dz_last, a slice ahead of the w0 cos that overwrites it (the same lane, the same address, in order): a wave-uniform
+      // branch around those stores would cut the regions below into blocks, and the compiler then sinks the range check's
+      // running maximum behind them, keeping (spilling) every slice's arguments until the tile's end.  (Sending them to a
+      // 2 KB dummy instead saved 0.03 ms and cost the two registers this kernel form does not have.)
       const bool keep_a = LOSS && l == n_mm;
-      float* gd = STORE ? (keep_a ? a.dz_last : a.deriv[l]) : nullptr;
-      float* ga = STORE ? (keep_a ? a.partial + (int64_t)blockIdx.x * fwd_slab_floats(kH) : a.act[l]) : nullptr;
-      const int amul = keep_a ? 0 : 1;
-      int64_t aoff[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) aoff[j] = keep_a ? (int64_t)(4 * lane + 256 * j) : goff[j];
+      float* gd = STORE ? (keep_a ? a.dz_last : a.deriv[l]) + gbase : nullptr;  // (the group's first row)
+      float* ga = STORE ? (keep_a ? a.dz_last : a.act[l]) + gbase : nullptr;
       const float w0 = a.w0;
 
       // the layer's operand: k-step ks contracts features 16 ks + 4 lh + (j & 3) + 8 (j >> 2) = registers 8 (ks & 1) + j of tile ks / 2
@@ -527,7 +524,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
                   if constexpr (fa)
                     put(gd, ft, fh, fl);
                   else
-                    put_a(ga, aoff, amul, ft, fh, fl);
+                    put(ga, ft, fh, fl);
                 }
               }
               if constexpr (mm && k == 0) wf[1] = read_wfrag(tB);
@@ -578,10 +575,9 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               for (int r = 0; r < 16; ++r) dq[r] = w0 * fix[(16 + r) * 64 + lane];
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                if (!keep_a)
-                  *reinterpret_cast<f32x4*>(ga + row * kH + feat0 + 32 * ti + 8 * q) =
-                      f32x4{out[ti][4 * q], out[ti][4 * q + 1], out[ti][4 * q + 2], out[ti][4 * q + 3]};
-                *reinterpret_cast<f32x4*>(gd + row * kH + feat0 + 32 * ti + 8 * q) =
+                *reinterpret_cast<f32x4*>(ga + (row * kH - gbase) + feat0 + 32 * ti + 8 * q) =
+                    f32x4{out[ti][4 * q], out[ti][4 * q + 1], out[ti][4 * q + 2], out[ti][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(gd + (row * kH - gbase) + feat0 + 32 * ti + 8 * q) =
                     f32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]};
               }
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch has been read: its bytes are the image again
@@ -600,7 +596,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
         stage(1, 3, f32x4{dd[0], dd[1], dd[2], dd[3]});
         f32x4 va[2], vd[2];
         unstage(0, 1, va), unstage(1, 1, vd);
-        put_a(ga, aoff, amul, t, 1, va), put(gd, t, 1, vd);
+        put(ga, t, 1, va), put(gd, t, 1, vd);
       }
     }
 
@@ -625,7 +621,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
         // from the w0 cos this kernel left in dz_last (dz = dy w_head (.) w0 cos, db_last: there -- re-reading w0 cos
         // here, a tile per round trip, cost 0.6 ms at config 3).  Rows beyond n repeat row n - 1 and add nothing.
         const bool live = g * kRows + 32 * wave + l31 < a.n;
-        const float diff = yv - a.target[row], dyv = diff * a.grad_scale, dys = live ? dyv : 0.f;
+        const float diff = yv - sm.xin[wave][kMaxIn + gpar][lane], dyv = diff * a.grad_scale, dys = live ? dyv : 0.f;
         if (lh == 0) a.dy_ws[row] = dyv;
         if (live && lh == 0) g_loss += diff * diff, g_bhead += dyv;
         float pw = 0.f;  // the even tile's reduced sums, waiting for the odd one

@@ -12,7 +12,6 @@ import torch
 from conftest import REL_TOL, assert_close
 from oracle import detrand
 from oracle import mlp as omlp
-from oracle import train as otrain
 
 pytestmark = pytest.mark.gpu
 
