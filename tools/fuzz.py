@@ -254,11 +254,15 @@ def run_siren(seed, pkg):
     x, y = torch.rand(n, dim, generator=g) * 2 - 1, torch.rand(n, 1, generator=g) * 2 - 1
     want_loss, _, grads = otrain.loss_and_grads(model, x, y)
     step = pkg.trainer.FusedStep(net, net.configure_optimizers())
-    _, ws = step.forward(x.cuda(), train=True)
-    step.backward(x.cuda(), y.cuda(), ws)
+    fused_loss = bool(seed & 1) and step.use_chain and step.chain_loss
+    if fused_loss:  # the training step's form: loss inside the forward kernel, the backward chain continuing it
+        step._chain_loss_pass(x.cuda(), y.cuda(), True, 1.0)
+    else:
+        _, ws = step.forward(x.cuda(), train=True)
+        step.backward(x.cuda(), y.cuda(), ws)
     got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
     want = torch.cat([g_.reshape(-1) for g_ in grads]).numpy()
-    return dict(dim=dim, hidden=hidden, layers=layers, n=n), \
+    return dict(dim=dim, hidden=hidden, layers=layers, n=n, fused_loss=fused_loss), \
         dict(loss=abs(float(step.loss) - float(want_loss)) / max(abs(float(want_loss)), 1e-30),
              grads=rel(got, want))
 
