@@ -896,7 +896,9 @@ __global__ __launch_bounds__(kThreadsR) void siren_backward_rows_kernel(const Bw
             if constexpr (ep && first) {
               // the derivative tile of tile i - 1 has landed (queued an iteration ago, twelve or more requests behind it)
               __builtin_amdgcn_sched_barrier(0);
+              RP_MARK(2)
               asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+              RP_MARK(6)  // derivative tile wait
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (mm && rg == 3) {

@@ -45,7 +45,7 @@ names = ["first layer", "operand split", "MFMAs + interleaved epilogue", "chunk 
          "last tile's epilogue", "head (+ loss tail)"]
 if mode == "bwd":  # (the forward kernel of the pass wrote first; the backward kernel's counters are what is left)
     names = ["head phase", "operand split", "MFMAs + epilogue", "chunk wait + barrier", "tail stores + bias sums",
-             "first layer's weight gradient"]
+             "first layer's weight gradient", "derivative tile wait"]
 total = t.sum(dim=2).mean()
 groups = n / 128 / 256
 print(f"{mode}: {a.elapsed_time(b):.3f} ms with counters; {total:.0f} cycles per wave, "
