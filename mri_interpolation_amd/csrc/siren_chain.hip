@@ -1152,7 +1152,23 @@ struct LossCall {
   int64_t n = -1;
   int hidden = 0, n_sine = 0, rows = -1;
 };
-thread_local LossCall g_last_loss_call;
+// (the last eight calls, by dz_last buffer: several networks may interleave their forward / backward pairs)
+thread_local LossCall g_loss_calls[8];
+thread_local int g_loss_call_next = 0;
+void remember_loss_call(const LossCall& c) {
+  for (LossCall& o : g_loss_calls)
+    if (o.dz_last == c.dz_last) {
+      o = c;
+      return;
+    }
+  g_loss_calls[g_loss_call_next] = c;
+  g_loss_call_next = (g_loss_call_next + 1) % 8;
+}
+const LossCall* find_loss_call(const void* dz_last) {
+  for (const LossCall& o : g_loss_calls)
+    if (o.dz_last == dz_last && o.n >= 0) return &o;
+  return nullptr;
+}
 }  // namespace
 }  // namespace mri
 
@@ -1196,8 +1212,8 @@ extern "C" int mri_siren_forward_loss(const float* x, const float* target, int64
   }
   hipStream_t st = (hipStream_t)stream;
   a.wsplit = wsplit;
-  g_last_loss_call = LossCall{workspace, dz_last, n, hidden, n_sine_layers,
-                              options().siren_rows && rows_backward_supported(hidden, n_sine_layers, dim_in, 1) ? 1 : 0};
+  remember_loss_call(LossCall{workspace, dz_last, n, hidden, n_sine_layers,
+                              options().siren_rows && rows_backward_supported(hidden, n_sine_layers, dim_in, 1) ? 1 : 0});
   if (int rc = split_weights(weight, n_sine_layers, hidden, false, wsplit, st)) return rc;
   if (int rc = forward_any(hidden, a, 2, st)) return rc;
   FwdReduceArgs r{};
@@ -1275,8 +1291,9 @@ extern "C" int mri_siren_backward(const float* x, const float* dy, int64_t n, in
   if (int rc = split_weights(weight, L, hidden, true, wtsplit, st)) return rc;
   const bool rows = options().siren_rows && rows_backward_supported(hidden, L, dim_in, head_done);
   if (head_done) {
-    const LossCall& c = g_last_loss_call;
-    MRI_REQUIRE(c.workspace == workspace && c.dz_last == dz[L - 1] && c.n == n && c.hidden == hidden && c.n_sine == L &&
+    const LossCall* found = find_loss_call(dz[L - 1]);
+    const LossCall c = found ? *found : LossCall{};
+    MRI_REQUIRE(found && c.workspace == workspace && c.n == n && c.hidden == hidden && c.n_sine == L &&
                     c.rows == (rows ? 1 : 0),
                 "mri_siren_backward(head_done = 1) continues the mri_siren_forward_loss call before it: same n, network, "
                 "dz[n_sine_layers - 1] = dz_last, workspace and \"siren_rows\" option (got n %lld / %lld, hidden %d / %d, "
