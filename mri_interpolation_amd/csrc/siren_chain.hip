@@ -1059,8 +1059,18 @@ __global__ __launch_bounds__(256) void siren_fwd_reduce_kernel(const FwdReduceAr
   const int H = r.hidden, slab = fwd_slab_floats(H);
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= slab) return;
+  // (eight loads in flight, the additions in slab order: a load per addition was 63 us of dependent round trips)
   float sum = 0.f;
-  for (int b = 0; b < r.slabs; ++b) sum += r.partial[(int64_t)b * slab + e];
+  const float* p = r.partial + e;
+  int b = 0;
+  for (; b + 8 <= r.slabs; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(b + j) * slab];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];
+  }
+  for (; b < r.slabs; ++b) sum += p[(int64_t)b * slab];
   if (e < H)
     r.d_w_head[e] += sum;
   else if (e < 2 * H)
