@@ -47,12 +47,13 @@ def _step(amd, net, x, y):
 
 
 @pytest.mark.parametrize("dim_in,n_layers,n", [(3, 5, 1), (3, 5, 127), (3, 5, 128), (3, 5, 129), (2, 2, 300),
-                                               (4, 3, 4097), (3, 5, 70001), (6, 3, 1000)])
+                                               (4, 3, 4097), (3, 5, 70001), (6, 3, 1000), (1, 8, 257)])
 def test_rows_kernels_against_oracle_and_image_kernels(amd, dim_in, n_layers, n):
     """Loss-mode forward + backward chain + weight gradients of the rows kernels: prediction, loss and every gradient
     against the float64 oracle at 1e-5, and against the LDS-image kernels (same arithmetic up to summation order) at
     2e-6.  Row counts cut the 128-row groups and the 32-row wave shares everywhere; dim_in = 6 takes the image
-    backward (the rows backward serves dim_in <= 4) with the rows forward in its plain training form."""
+    backward (the rows backward serves dim_in <= 4) with the rows forward in its plain training form; 8 layers is
+    MRI_SIREN_MAX_LAYERS."""
     lib = amd.lib.load()
     net, params = _net(amd, dim_in, n_layers, 900 + n_layers + dim_in)
     x = torch.from_numpy(detrand.uniform(n * dim_in, n + 3, -1.0, 1.0).reshape(n, dim_in)).cuda()
