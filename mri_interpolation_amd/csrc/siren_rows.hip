@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               if constexpr (n == 0) ux = acc[ti & 1][r0], uy = acc[ti & 1][r0 + 1];
               if constexpr (n == 1) ux += bx, uy += by;
               if constexpr (n == 2) ux *= w0, uy *= w0;
-              if constexpr (n == 3) amax = fmaxf(amax, fmaxf(fabsf(ux), fabsf(uy)));
+              if constexpr (n == 3) amax = __builtin_fmaxf(__builtin_fmaxf(amax, fabsf(ux)), fabsf(uy));  // (one v_max3 with |.| modifiers)
               if constexpr (n == 4) kx = ux * 0.636619772367581343f, ky = uy * 0.636619772367581343f;
               if constexpr (n == 5) kx = rintf(kx), ky = rintf(ky);
               if constexpr (n == 6) qx = (int)kx, qy = (int)ky;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kThreadsR) void siren_forward_rows_kernel(const Cha
               if constexpr (n == 23) sx = nx ? ax : -ax, sy = ny ? ay : -ay;
               // (a use in front of the range check: nothing sinks behind its branch.  Of the SIGNED values: |s| does not need
               // the quadrant's sign, and the inference form then kept -- spilled -- sign bits and magnitudes for later)
-              if constexpr (n == 25) smax = fmaxf(smax, fmaxf(sx, sy));
+              if constexpr (n == 25 && !STORE) smax = fmaxf(smax, fmaxf(sx, sy));  // (the training forms' stores are such a use)
               if constexpr (n == 24) out[ti][r0] = sx, out[ti][r0 + 1] = sy;
               // (26: a spare slot of the inference form)
               if constexpr (n == 27) ax = ex ? csx : snx, ay = ey ? csy : sny;
